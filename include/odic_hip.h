@@ -1,0 +1,214 @@
+/*
+ * odic_hip.h — C ABI of libodic_hip.so: hand-written HIP (gfx950 / CDNA4) kernels for the
+ * ExpansionNet v2 inference path (Swin-L/384 backbone → expansion encoder → beam-search decoder).
+ *
+ * The reference (nighting0le01/On_Device_Image_Captioning) has NO native code and NO FFI: its
+ * boundary is a Python class contract.  This header is therefore the boundary
+ * that the build's own Python host code (the on_device_image_captioning_amd package, ctypes) binds; each
+ * entry point names the reference computation it replaces (file:line under /root/reference).
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless noted.
+ *   - no allocation, no ownership transfer, no host synchronisation inside any entry point: the
+ *     caller allocates outputs/workspaces and passes the HIP stream (hipStream_t as void*).
+ *     All entry points are therefore legal inside a stream capture (hipGraph).
+ *   - return 0 on success, a negative ODIC_E* code on a rejected argument, or the positive
+ *     hipError_t of a failed launch.  Nothing is printed.
+ *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ *   - dtype codes: ODIC_F32 = 0 (float), ODIC_BF16 = 1 (bfloat16, raw uint16 storage).
+ */
+#ifndef ODIC_HIP_H
+#define ODIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODIC_F32 0
+#define ODIC_BF16 1
+
+#define ODIC_ACT_NONE 0
+#define ODIC_ACT_GELU 1    /* exact erf GELU (nn.GELU, swin_transformer_mod.py:87) */
+#define ODIC_ACT_RELU 2
+#define ODIC_ACT_SIGMOID 3
+
+#define ODIC_EINVAL (-1)   /* bad shape / alignment / enum */
+#define ODIC_ENULL (-2)    /* required pointer is NULL */
+#define ODIC_EUNSUPPORTED (-3)
+
+/* ABI version of this header; bumped on any signature change. */
+#define ODIC_ABI_VERSION 1
+int odic_abi_version(void);
+
+/* Human-readable build string ("gfx950 hipcc ..."), static storage. */
+const char* odic_build_info(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:   out = act(alpha * A·Wᵀ + bias) + residual
+ *   A [M,K] (lda), W [N,K] (ldw) — the nn.Linear weight layout, so no transposes anywhere.
+ *   bias: fp32, NULL or length N (bias_axis 0, per column) / length M (bias_axis 1, per row)
+ *   residual: fp32 [M,N] (ldr) or NULL; out: `out_dtype` [M,N] (ldc)
+ *   batch > 1: operands advance by the given element strides (0 = shared operand).
+ * Replaces every nn.Linear on the path: swin_transformer_mod.py:190,212 (qkv/proj), :94-97
+ * (Mlp fc1/fc2), :396 (PatchMerging.reduction), layers.py:49-51,99,154-161,274-276,293,306-307,
+ * End_ExpansionNet_v2.py:82,97,134,137.
+ * in_dtype ODIC_BF16: MFMA 16x16x32 bf16, fp32 accumulate; needs K % 64 == 0, lda/ldw % 8 == 0,
+ *   16-byte aligned A/W.   in_dtype ODIC_F32: MFMA 16x16x4 f32 (exact fp32 FMA chain), any M,N,K.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct odic_gemm_args {
+  const void* A; const void* W; const float* bias; const float* residual; void* out;
+  int32_t M, N, K;
+  int64_t lda, ldw, ldr, ldc;
+  int32_t batch;
+  int64_t strideA, strideW, strideBias, strideR, strideC;
+  float alpha;
+  int32_t act;        /* ODIC_ACT_* */
+  int32_t bias_axis;  /* 0: bias[n]   1: bias[m] */
+  int32_t in_dtype;   /* dtype of A and W */
+  int32_t out_dtype;  /* dtype of out */
+} odic_gemm_args;
+int odic_gemm(const odic_gemm_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (eps inside sqrt, biased variance — torch.nn.LayerNorm).
+ *   x fp32 [M,C] (ldx) → out `out_dtype` [M,C] contiguous.   C % 4 == 0, C <= 8192.
+ * Replaces swin_transformer_mod.py:309,338 (norm1/norm2), :639 (final norm), layers.py:119,121,
+ * 225,228,232 and the reduce norms End_ExpansionNet_v2.py:99,135.
+ * ------------------------------------------------------------------------------------------- */
+int odic_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, void* out,
+                   int32_t M, int32_t C, float eps, int32_t out_dtype, void* stream);
+
+/* PatchMerging gather + LayerNorm(4C)  (swin_transformer_mod.py:386-395):
+ *   x fp32 [B, res*res, C] → out `out_dtype` [B, (res/2)², 4C]; channel blocks in the order
+ *   (0,0),(1,0),(0,1),(1,1) of the 2x2 neighbourhood (row offset, col offset). */
+int odic_patch_merge_layernorm(const float* x, const float* gamma, const float* beta, void* out,
+                               int32_t B, int32_t res, int32_t C, float eps, int32_t out_dtype,
+                               void* stream);
+
+/* PatchEmbed: Conv2d(in_chans→C, k=s=patch) + flatten + LayerNorm(C)
+ * (swin_transformer_mod.py:511-519).  img fp32 [B,in_chans,H,W]; w fp32 [C,in_chans*patch*patch];
+ * out fp32 [B,(H/patch)*(W/patch),C]. */
+int odic_patch_embed(const float* img, const float* w, const float* b, const float* gamma,
+                     const float* beta, float* out, int32_t B, int32_t in_chans, int32_t H,
+                     int32_t W, int32_t patch, int32_t C, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Swin (shifted-)window attention core  (WindowAttention.forward swin_transformer_mod.py:193-211
+ * plus the roll / window_partition / window_reverse / roll index maps of :312-334, folded into the
+ * kernel's loads and stores so no permuted copy is ever materialised):
+ *   qkv  `dtype` [B*res*res, 3C]   token-major output of the qkv Linear, columns (3, heads, 32)
+ *   bias_table fp32 [(2ws-1)², heads]   relative_position_bias_table; the index buffer (:163-173)
+ *        and the SW-MSA mask (:281-297, values 0/-100) are recomputed from coordinates.
+ *   out  `dtype` [B*res*res, C]    softmax(q·kᵀ·scale + bias + mask)·v, heads concatenated,
+ *        written back at the un-shifted token positions (ready for the proj Linear).
+ * head_dim is 32 (every Swin-L stage), ws*ws <= 144, res % ws == 0, 0 <= shift < ws.
+ * ------------------------------------------------------------------------------------------- */
+int odic_window_attention(const void* qkv, const float* bias_table, void* out, int32_t B,
+                          int32_t res, int32_t C, int32_t heads, int32_t ws, int32_t shift,
+                          float scale, int32_t dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Static expansion (encoder) helpers — layers.py:45-102.  The contractions run through
+ * odic_gemm; these kernels do the relu/mask/L1-normalise steps in between.
+ *   z fp32 [B, nq, S]: Q·Kᵀ/sqrt(d).
+ *   fw:  pos = relu(z)·valid, neg = relu(-z)·valid, each row divided by (rowsum + eps) over S
+ *        (layers.py:56-61) → pos_fw, neg_fw fp32 [B, nq, S].  enc_len[b] = #valid keys (int32 [B]).
+ *   bw:  relu(±zᵀ) [B, S, nq], each of the `ngroups` column groups L1-normalised separately
+ *        (layers.py:67-79) and pre-divided by ngroups (:84-85) → pos_bw, neg_bw fp32 [B, S, nq].
+ *   group_meta: device int32 [ngroups+1+nq] = exclusive prefix sums of the group sizes (last = nq)
+ *        followed by the group index of every query row.
+ *   colsum_ws: fp32 scratch [B*ngroups*2*S].
+ * ------------------------------------------------------------------------------------------- */
+int odic_stcexp_normalize(const float* z, const int32_t* enc_len, const int32_t* group_meta,
+                          int32_t ngroups, float* pos_fw, float* neg_fw, float* pos_bw,
+                          float* neg_bw, float* colsum_ws, int32_t B, int32_t nq, int32_t S,
+                          float eps, void* stream);
+
+/* out = x + sigmoid(sel_pre)·a + (1-sigmoid(sel_pre))·b     (layers.py:99-100 + the residual add of
+ * EncoderLayer :120); all fp32 [M, d] with row strides. */
+int odic_selector_mix(const float* x, int64_t ldx, const float* sel_pre, int64_t lds,
+                      const float* a, int64_t lda, const float* b, int64_t ldb, float* out,
+                      int64_t ldo, int32_t M, int32_t d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Incremental decoder step (exact because the decoder is causal).
+ * N = number of live sequences (images × beams), laid out image-major: seq = img*beams + beam.
+ * `pos` (device int32 scalar) is the position being processed; kernels read it from memory so one
+ * captured graph can be replayed for every step.
+ * ------------------------------------------------------------------------------------------- */
+
+/* y[n,:] = embed[tok[n]]·sqrt(d) + pos_table[pos]   (layers.py:16-17, End_ExpansionNet_v2.py:118-121) */
+int odic_dec_embed(const int64_t* tokens, const float* embed, const float* pos_table,
+                   const int32_t* pos, float* y, int64_t ldy, int32_t N, int32_t d, float scale,
+                   void* stream);
+
+/* Dynamic expansion for the newest position (layers.py:152-204), with per-position caches.
+ *   lin fp32 [N, >=5d] (ldlin): cond | key | class_a | class_b | selector-pre-activation of
+ *        LN1(y) at `pos`
+ *   qexp, bexp fp32 [E, d]: query_exp_vectors / bias_exp_vectors
+ *   caches (fp32), indexed [pos][seq_slot]:  cond_c, key_c, va_c, vb_c  [T, N, d]
+ *                                            afull_c, bfull_c  [T, N, E, d] (class_a/b + bias, :199-200)
+ *                                            qk_c [T, N, E]   (query_exp[e]·key of that position)
+ *   anc int32 [N, T]: for sequence n and position j < pos, the slot (sequence index) whose cache
+ *        entry at j belongs to n's history (beam re-ordering without copying caches); position
+ *        `pos` itself is always slot n.
+ *   row_valid int32 [N]: 0 → padded row (finished beam): the block contributes 0 (masked rows of
+ *        utils/masking.py:37-47), caches are still written.
+ *   y_in fp32 [N,d] (ldy_in) → y fp32 [N,d] (ldy):  y = y_in + sel·A' + (1-sel)·B'  (may alias).
+ *   T <= 128, E <= 32.
+ */
+int odic_dynexp_step(const float* lin, int64_t ldlin, const float* qexp, const float* bexp,
+                     float* cond_c, float* key_c, float* va_c, float* vb_c, float* afull_c,
+                     float* bfull_c, float* qk_c, const int32_t* anc, const int32_t* row_valid,
+                     const int32_t* pos, const float* y_in, int64_t ldy_in, float* y, int64_t ldy,
+                     int32_t N, int32_t T, int32_t d, int32_t E, float eps, void* stream);
+
+/* Cross attention of one query row per sequence against per-IMAGE cached K/V (layers.py:266-295;
+ * the reference re-projects K/V of the 144 encoder tokens every step for every beam copy).
+ *   q fp32 [N, d] (ldq; already Wq-projected, bias included);
+ *   kv fp32 [n_img, S, ldkv]: projected keys at column koff, values at column voff;
+ *   enc_len int32 [n_img]; beams = N / n_img; row_valid as above (0 → all scores masked to -1e4,
+ *   i.e. a uniform average over all S positions, exactly what masked_fill + softmax gives).
+ *   out fp32 [N, d] (ldo) = softmax(q·kᵀ/sqrt(d/heads))·v, heads concatenated.  d % 64 == 0. */
+int odic_cross_attn_step(const float* q, int64_t ldq, const float* kv, int64_t ldkv, int32_t koff,
+                         int32_t voff, const int32_t* enc_len, const int32_t* row_valid, float* out,
+                         int64_t ldo, int32_t N, int32_t n_img, int32_t S, int32_t d, int32_t heads,
+                         void* stream);
+
+/* log_softmax over V + top-k (captioning_model.py:126-127,162-170).  logits fp32 [N, V] (ldl);
+ * writes logp_out fp32 [N, V] (ldp) if non-NULL, top_val fp32 [N,k] / top_idx int32 [N,k] sorted
+ * descending (ties: lower index first).  k <= 16. */
+int odic_logsoftmax_topk(const float* logits, int64_t ldl, float* logp_out, int64_t ldp,
+                         float* top_val, int32_t* top_idx, int32_t N, int32_t V, int32_t k,
+                         void* stream);
+
+/* Beam bookkeeping of one search step on device (captioning_model.py:172-223; the call with
+ * *pos == 0 is the seeding of :126-140).  All arrays are device resident.
+ *   cand_val/cand_idx [n_img*beams, beams]: per-sequence top-k log-probs / words
+ *   tokens int64 [n_img, beams, T] prefixes (tokens[:, :, 0] = SOS before the first call),
+ *   logprobs fp32 [n_img, beams, T] per-token log-probs (slot 0 = 0), anc int32 [N, T],
+ *   cumul fp32 [N], n_elem int32 [N] (length incl. SOS/EOS), has_eos int32 [N],
+ *   row_valid int32 [N] (output: 1 while the beam was still growing), next_tok int64 [N] (output:
+ *   token to feed at the next step), pos int32 scalar (incremented at the end),
+ *   done int32 scalar (set to 1 when every beam has stopped growing, :222).
+ */
+typedef struct odic_beam_state {
+  int64_t* tokens; float* logprobs; int32_t* anc;
+  float* cumul; int32_t* n_elem; int32_t* has_eos; int32_t* row_valid; int64_t* next_tok;
+  int32_t* pos; int32_t* done;
+} odic_beam_state;
+int odic_beam_step(const float* cand_val, const int32_t* cand_idx, const odic_beam_state* st,
+                   int32_t n_img, int32_t beams, int32_t T, int64_t eos_idx, void* stream);
+
+/* Final selection (captioning_model.py:225-241): score = cumul / n_elem, descending order per
+ * image → order int32 [n_img, beams], score fp32 [n_img, beams]. */
+int odic_beam_finalize(const odic_beam_state* st, int32_t* order, float* score, int32_t n_img,
+                       int32_t beams, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODIC_HIP_H */

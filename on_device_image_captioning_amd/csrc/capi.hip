@@ -1,0 +1,27 @@
+// C-ABI glue: argument validation + dtype dispatch for the entry points whose kernels live in
+// several translation units.  No state, no allocation, no synchronisation.
+#include "odic_common.h"
+
+int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream);
+int odic_gemm_f32_launch(const odic_gemm_args* a, hipStream_t stream);
+
+extern "C" int odic_abi_version(void) { return ODIC_ABI_VERSION; }
+
+extern "C" const char* odic_build_info(void) {
+  return "libodic_hip gfx950 (CDNA4) " __DATE__ " " __TIME__ " hipcc " __clang_version__;
+}
+
+extern "C" int odic_gemm(const odic_gemm_args* a, void* stream) {
+  if (!a || !a->A || !a->W || !a->out) return ODIC_ENULL;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return ODIC_EINVAL;
+  if (a->lda < a->K || a->ldw < a->K || a->ldc < a->N) return ODIC_EINVAL;
+  if (a->residual && a->ldr < a->N) return ODIC_EINVAL;
+  if (a->act < ODIC_ACT_NONE || a->act > ODIC_ACT_SIGMOID) return ODIC_EINVAL;
+  if (a->bias_axis != 0 && a->bias_axis != 1) return ODIC_EINVAL;
+  if (a->out_dtype != ODIC_F32 && a->out_dtype != ODIC_BF16) return ODIC_EINVAL;
+  if (a->batch > 65535) return ODIC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->in_dtype == ODIC_BF16) return odic_gemm_bf16_launch(a, s);
+  if (a->in_dtype == ODIC_F32) return odic_gemm_f32_launch(a, s);
+  return ODIC_EINVAL;
+}

@@ -1,0 +1,524 @@
+// Incremental decoder-step kernels for gfx950 (fp32) — SURVEY §8 rows A13-A19.
+//
+// The reference re-runs the whole prefix every step (O(T²)); its decoder is strictly causal, so we
+// process ONE new position per step against per-position caches.  Beam re-ordering never moves a
+// cache: `anc[n][j]` names the slot (sequence index at the time position j was processed) whose
+// entry belongs to sequence n's history.  Every kernel reads the current position from device
+// memory (`*pos`) so the same captured graph serves every step.
+//
+//   dec_embed_kernel         y = embed[tok]·sqrt(d) + pos_table[pos]
+//   dynexp_step_kernel       DynamicExpansionBlock for the newest row (layers.py:152-204)
+//   cross_attn_step_kernel   MultiHeadAttention against per-image cached K/V (layers.py:266-295)
+//   logsoftmax_topk_kernel   log_softmax over the vocabulary + top-k (captioning_model.py:162-170)
+//   beam_step_kernel         candidate masking, k·k selection, prefix/ancestor re-gather (:172-223)
+//   beam_finalize_kernel     length-normalised ranking (:225-227)
+#include "odic_common.h"
+
+namespace {
+
+constexpr int MAX_T = 128;     // max decode positions supported by the LDS scratch below
+constexpr int MAX_E = 32;      // max expansion vectors per position
+constexpr int MAX_K = 16;      // max beam size
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dec_embed_kernel(const long long* __restrict__ tokens,
+                                                        const float* __restrict__ embed,
+                                                        const float* __restrict__ pos_table,
+                                                        const int* __restrict__ pos, float* __restrict__ y,
+                                                        long ldy, int N, int d, float scale) {
+  const int n = blockIdx.x;
+  const long tok = tokens[n];
+  const int p = *pos;
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    y[n * ldy + c] = embed[tok * d + c] * scale + pos_table[(long)p * d + c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// One block per sequence.  With t = *pos and slot(j) = (j < t ? anc[n][j] : n):
+//   forward  z_fw[e][j] = (qexp[e] + cond_t)·key_j / sqrt(d)            j <= t
+//            A[e] = Σ_j relu(z_fw)[e][j]/(Σ_j relu(z_fw)[e][j] + eps) · va_j          (same with -z, vb)
+//            afull_t[e] = A[e] + bexp[e] + cond_t                                       (cached)
+//   backward z_bw[j][e] = (qexp[e] + cond_j)·key_t / sqrt(d)            j <= t
+//            out_a = Σ_{j,e} relu(z_bw)[j][e]/(Σ relu(z_bw) + eps) · afull_j[e]        (same with -z, bfull)
+//   y_out = y_in + σ(sel)·out_a + (1-σ(sel))·out_b        (nothing is added on a padded row)
+// The dot products split as qexp[e]·key + cond·key; qexp[e]·key_j is cached per position (qk_c).
+// ---------------------------------------------------------------------------------------------
+struct DynParams {
+  const float* lin; long ldlin; const float* qexp; const float* bexp;
+  float* cond_c; float* key_c; float* va_c; float* vb_c; float* afull_c; float* bfull_c; float* qk_c;
+  const int* anc; const int* row_valid; const int* pos; const float* y_in; long ldyi; float* y; long ldy;
+  int N, T, d, E; float eps;
+};
+
+__global__ __launch_bounds__(256) void dynexp_step_kernel(DynParams p) {
+  extern __shared__ float sm[];
+  const int d = p.d, E = p.E, n = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int t = *p.pos;
+  float* cond_t = sm;                  // [d]
+  float* key_t = cond_t + d;           // [d]
+  float* dk = key_t + d;               // [MAX_T]  cond_t·key_j
+  float* ck = dk + MAX_T;              // [MAX_T]  cond_j·key_t
+  float* qk_t = ck + MAX_T;            // [MAX_E]  qexp[e]·key_t
+  float* nfw = qk_t + MAX_E;           // [2*MAX_E] 1/(Σ_j relu(±z_fw[e][·]) + eps)
+  float* red = nfw + 2 * MAX_E;        // [8]
+  int* slot = (int*)(red + 8);         // [MAX_T]
+
+  const float* lin = p.lin + (long)n * p.ldlin;
+  const float inv_sqrt_d = rsqrtf((float)d);
+  const long NT = (long)p.N;
+
+  for (int c = tid; c < d; c += 256) {
+    const float cv = lin[c], kv = lin[d + c];
+    cond_t[c] = cv; key_t[c] = kv;
+    const long o = ((long)t * NT + n) * d + c;
+    p.cond_c[o] = cv; p.key_c[o] = kv; p.va_c[o] = lin[2 * d + c]; p.vb_c[o] = lin[3 * d + c];
+  }
+  for (int j = tid; j <= t; j += 256) slot[j] = j < t ? p.anc[(long)n * p.T + j] : n;
+  __syncthreads();
+
+  // ---- dot products: one wave per item, lanes stride over d
+  //   items 0..E-1: qk_t[e];  E..E+t: dk[j] (j = item-E, 0..t);  E+t+1 .. E+2t: ck[j] (j = 0..t-1)
+  const int nitems = E + (t + 1) + t;
+  for (int it = wave; it < nitems; it += 4) {
+    const float* a; const float* b;
+    if (it < E) { a = p.qexp + (long)it * d; b = key_t; }
+    else if (it < E + t + 1) {
+      const int j = it - E;
+      a = cond_t; b = j < t ? p.key_c + ((long)j * NT + slot[j]) * d : key_t;
+    } else {
+      const int j = it - E - t - 1;
+      a = p.cond_c + ((long)j * NT + slot[j]) * d; b = key_t;
+    }
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s = fmaf(a[c], b[c], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+      if (it < E) { qk_t[it] = s; p.qk_c[((long)t * NT + n) * E + it] = s; }
+      else if (it < E + t + 1) dk[it - E] = s;
+      else ck[it - E - t - 1] = s;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) ck[t] = dk[t];           // cond_t·key_t
+  __syncthreads();
+
+  // ---- forward normalisers: thread e sums over j
+  if (tid < E) {
+    float sp = 0.f, sn = 0.f;
+    for (int j = 0; j <= t; ++j) {
+      const float q = j < t ? p.qk_c[((long)j * NT + slot[j]) * E + tid] : qk_t[tid];
+      const float z = (q + dk[j]) * inv_sqrt_d;
+      sp += fmaxf(z, 0.f); sn += fmaxf(-z, 0.f);
+    }
+    nfw[tid] = 1.0f / (sp + p.eps);
+    nfw[MAX_E + tid] = 1.0f / (sn + p.eps);
+  }
+  // ---- backward normaliser: Σ over (j, e)
+  float bp = 0.f, bn = 0.f;
+  for (int i = tid; i < (t + 1) * E; i += 256) {
+    const int j = i / E, e = i - j * E;
+    const float z = (qk_t[e] + ck[j]) * inv_sqrt_d;
+    bp += fmaxf(z, 0.f); bn += fmaxf(-z, 0.f);
+  }
+  const float ibp = 1.0f / (block_sum(bp, red) + p.eps);
+  const float ibn = 1.0f / (block_sum(bn, red) + p.eps);
+  __syncthreads();
+
+  const int valid = p.row_valid[n];
+  // ---- per-channel accumulation (thread owns channels c = tid, tid+256, ...)
+  for (int c = tid; c < d; c += 256) {
+    float fa[MAX_E], fb[MAX_E];
+#pragma unroll
+    for (int e = 0; e < MAX_E; ++e) { fa[e] = 0.f; fb[e] = 0.f; }
+    for (int j = 0; j <= t; ++j) {
+      const long o = ((long)j * NT + slot[j]) * d + c;
+      const float va = j < t ? p.va_c[o] : lin[2 * d + c];
+      const float vb = j < t ? p.vb_c[o] : lin[3 * d + c];
+      const float dkj = dk[j];
+      const float* qkj = j < t ? p.qk_c + ((long)j * NT + slot[j]) * E : qk_t;
+#pragma unroll
+      for (int e = 0; e < MAX_E; ++e) {
+        if (e < E) {
+          const float z = (qkj[e] + dkj) * inv_sqrt_d;
+          fa[e] = fmaf(fmaxf(z, 0.f) * nfw[e], va, fa[e]);
+          fb[e] = fmaf(fmaxf(-z, 0.f) * nfw[MAX_E + e], vb, fb[e]);
+        }
+      }
+    }
+    const float cv = cond_t[c];
+    float oa = 0.f, ob = 0.f;
+    // newest position: afull/bfull straight from registers, and into the cache
+#pragma unroll
+    for (int e = 0; e < MAX_E; ++e) {
+      if (e < E) {
+        const float bias = p.bexp[(long)e * d + c] + cv;
+        const float af = fa[e] + bias, bf = fb[e] + bias;
+        const long o = (((long)t * NT + n) * E + e) * d + c;
+        p.afull_c[o] = af; p.bfull_c[o] = bf;
+        const float z = (qk_t[e] + ck[t]) * inv_sqrt_d;
+        oa = fmaf(fmaxf(z, 0.f) * ibp, af, oa);
+        ob = fmaf(fmaxf(-z, 0.f) * ibn, bf, ob);
+      }
+    }
+    for (int j = 0; j < t; ++j) {
+      const long base = (((long)j * NT + slot[j]) * E) * d + c;
+      const float ckj = ck[j];
+      for (int e = 0; e < E; ++e) {
+        const float z = (qk_t[e] + ckj) * inv_sqrt_d;
+        oa = fmaf(fmaxf(z, 0.f) * ibp, p.afull_c[base + (long)e * d], oa);
+        ob = fmaf(fmaxf(-z, 0.f) * ibn, p.bfull_c[base + (long)e * d], ob);
+      }
+    }
+    float yv = p.y_in[(long)n * p.ldyi + c];
+    if (valid) {
+      const float sg = 1.0f / (1.0f + expf(-lin[4 * d + c]));
+      yv += sg * oa + (1.0f - sg) * ob;
+    }
+    p.y[(long)n * p.ldy + c] = yv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One block per sequence.  kv: [n_img, S, ldkv] with K at column koff and V at column voff.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __restrict__ q, long ldq,
+                                                              const float* __restrict__ kv, long ldkv, int koff,
+                                                              int voff, const int* __restrict__ enc_len,
+                                                              const int* __restrict__ row_valid,
+                                                              float* __restrict__ out, long ldo, int beams, int S,
+                                                              int d, int heads) {
+  extern __shared__ float sm[];
+  float* qs = sm;                 // [d]
+  float* sc = qs + d;             // [heads][S]
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int img = n / beams;
+  const int dk = d / heads;
+  const int len = enc_len[img];
+  const int valid = row_valid[n];
+  const float inv = rsqrtf((float)dk);
+  const float* kvb = kv + (long)img * S * ldkv;
+  for (int c = tid; c < d; c += 256) qs[c] = q[(long)n * ldq + c];
+  __syncthreads();
+
+  // scores: wave per key; lane owns a contiguous run of `per` channels, a head spans dk/per lanes
+  const int per = d / 64;                 // d % 64 == 0 (checked on the host), per divides dk
+  const int lanes_per_head = dk / per;
+  for (int s = wave; s < S; s += 4) {
+    const float* kr = kvb + (long)s * ldkv + koff + lane * per;
+    float acc = 0.f;
+    for (int i = 0; i < per; ++i) acc = fmaf(qs[lane * per + i], kr[i], acc);
+    for (int o = 1; o < lanes_per_head; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if ((lane % lanes_per_head) == 0) {
+      const int h = lane / lanes_per_head;
+      float v = acc * inv;
+      if (!valid || s >= len) v = -1e4f;      // masked_fill(mask == 0, -1e4), layers.py:286
+      sc[h * S + s] = v;
+    }
+  }
+  __syncthreads();
+  // softmax per head: wave w handles heads w, w+4, ...
+  for (int h = wave; h < heads; h += 4) {
+    float m = -INFINITY;
+    for (int s = lane; s < S; s += 64) m = fmaxf(m, sc[h * S + s]);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int s = lane; s < S; s += 64) { const float e = expf(sc[h * S + s] - m); sc[h * S + s] = e; l += e; }
+    l = wave_sum(l);
+    const float il = 1.0f / l;
+    for (int s = lane; s < S; s += 64) sc[h * S + s] *= il;
+  }
+  __syncthreads();
+  for (int c = tid; c < d; c += 256) {
+    const int h = c / dk;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc = fmaf(sc[h * S + s], kvb[(long)s * ldkv + voff + c], acc);
+    out[(long)n * ldo + c] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One block per row: max, log-sum-exp, then k rounds of block arg-max (ties → lower index).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __restrict__ logits, long ldl,
+                                                              float* __restrict__ logp_out, long ldp,
+                                                              float* __restrict__ top_val, int* __restrict__ top_idx,
+                                                              int V, int k) {
+  __shared__ float red[8];
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  __shared__ int taken[MAX_K];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = logits + (long)n * ldl;
+  float m = -INFINITY;
+  for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int i = tid; i < V; i += 256) s += expf(x[i] - m);
+  s = block_sum(s, red);
+  const float lse = m + logf(s);
+  if (logp_out)
+    for (int i = tid; i < V; i += 256) logp_out[(long)n * ldp + i] = x[i] - lse;
+  for (int r = 0; r < k; ++r) {
+    float best = -INFINITY; int besti = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+      bool skip = false;
+      for (int q = 0; q < r; ++q) skip |= (taken[q] == i);
+      const float v = x[i];
+      if (!skip && (v > best || (v == best && i < besti))) { best = v; besti = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(besti, o, 64);
+      if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+      float b = bv[0]; int ix = bi[0];
+      for (int w = 1; w < 4; ++w)
+        if (bv[w] > b || (bv[w] == b && bi[w] < ix)) { b = bv[w]; ix = bi[w]; }
+      taken[r] = ix;
+      top_val[(long)n * k + r] = b - lse;
+      top_idx[(long)n * k + r] = ix;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Beam bookkeeping: ONE block; image b is handled by wave (b & 3) in round (b >> 2).  All waves run
+// the same number of rounds so the block barriers are uniform.  The prefix / log-prob / ancestor
+// rows of an image are permuted IN PLACE: a lane owns whole columns j, reads the k parent values
+// of its column first and then writes the k new rows.
+// ---------------------------------------------------------------------------------------------
+struct BeamParams {
+  const float* cand_val; const int* cand_idx;
+  long long* tok; float* lp; int* anc;
+  float* cumul; int* n_elem; int* has_eos; int* row_valid; long long* next_tok;
+  int* pos; int* done;
+  int n_img, k, T; long long eos;
+};
+
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
+  __shared__ int s_parent[4][MAX_K];
+  __shared__ int s_word[4][MAX_K];
+  __shared__ float s_lp[4][MAX_K];
+  __shared__ float s_cumul[4][MAX_K];
+  __shared__ int s_alive[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = p.k, T = p.T;
+  const int t = *p.pos;                 // position just processed; prefix length is t+1
+  int alive_any = 0;
+
+  for (int b0 = 0; b0 < p.n_img; b0 += 4) {
+    const int b = b0 + wave;
+    const bool active = b < p.n_img;
+    // ---- selection (lane 0): top-k of the k·k masked totals (first step: the k seeds of beam 0)
+    if (active && lane == 0) {
+      if (t == 0) {
+        for (int r = 0; r < k; ++r) {
+          s_parent[wave][r] = 0;
+          s_word[wave][r] = p.cand_idx[((long)b * k) * k + r];
+          s_lp[wave][r] = p.cand_val[((long)b * k) * k + r];
+        }
+      } else {
+        float tot[MAX_K * MAX_K];
+        for (int j = 0; j < k; ++j) {
+          const int dn = p.has_eos[b * k + j];
+          const float cu = p.cumul[b * k + j];
+          for (int c = 0; c < k; ++c) {
+            const float v = dn ? (c == 0 ? 0.0f : -999.0f) : p.cand_val[((long)b * k + j) * k + c];
+            tot[j * k + c] = cu + v;
+          }
+        }
+        for (int r = 0; r < k; ++r) {
+          int bi = 0; float bvv = -INFINITY;
+          for (int i = 0; i < k * k; ++i)
+            if (tot[i] > bvv) { bvv = tot[i]; bi = i; }
+          tot[bi] = -INFINITY;
+          const int j = bi / k, c = bi - j * k;
+          const int dn = p.has_eos[b * k + j];
+          s_parent[wave][r] = j;
+          s_word[wave][r] = p.cand_idx[((long)b * k + j) * k + c];
+          s_lp[wave][r] = dn ? (c == 0 ? 0.0f : -999.0f) : p.cand_val[((long)b * k + j) * k + c];
+        }
+      }
+      // cumulative score = re-summed per-token log-probs of the parent prefix + the new one (:213)
+      for (int r = 0; r < k; ++r) {
+        const long src = ((long)b * k + s_parent[wave][r]) * T;
+        float cs = 0.f;
+        for (int j = 0; j <= t; ++j) cs += p.lp[src + j];
+        s_cumul[wave][r] = cs + s_lp[wave][r];
+      }
+    }
+    __syncthreads();
+    if (active) {
+      // ---- in-place column-wise permutation of the k rows, then append the new word
+      const long base = (long)b * k * T;
+      for (int j = lane; j <= t; j += 64) {
+        long long tv[MAX_K]; float lv[MAX_K]; int av[MAX_K];
+#pragma unroll
+        for (int r = 0; r < MAX_K; ++r) {
+          if (r < k) {
+            const long src = base + (long)s_parent[wave][r] * T + j;
+            tv[r] = p.tok[src]; lv[r] = p.lp[src];
+            av[r] = j < t ? p.anc[src] : b * k + s_parent[wave][r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < MAX_K; ++r) {
+          if (r < k) {
+            const long dst = base + (long)r * T + j;
+            p.tok[dst] = tv[r]; p.lp[dst] = lv[r]; p.anc[dst] = av[r];
+          }
+        }
+      }
+      if (lane == 0) {
+        int pe[MAX_K], ne[MAX_K];
+        for (int r = 0; r < k; ++r) {
+          const int par = s_parent[wave][r];
+          pe[r] = t == 0 ? 0 : p.has_eos[b * k + par];
+          ne[r] = t == 0 ? 1 : p.n_elem[b * k + par];
+        }
+        for (int r = 0; r < k; ++r) {
+          const long dst = base + (long)r * T;
+          p.tok[dst + t + 1] = (long long)s_word[wave][r];
+          p.lp[dst + t + 1] = s_lp[wave][r];
+          p.cumul[b * k + r] = s_cumul[wave][r];
+          p.n_elem[b * k + r] = ne[r] + (pe[r] ? 0 : 1);
+          p.has_eos[b * k + r] = (pe[r] || ((long long)s_word[wave][r] == p.eos)) ? 1 : 0;
+          p.row_valid[b * k + r] = pe[r] ? 0 : 1;
+          p.next_tok[b * k + r] = (long long)s_word[wave][r];
+          if (!pe[r]) alive_any = 1;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) s_alive[wave] = alive_any;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int alive = s_alive[0] | s_alive[1] | s_alive[2] | s_alive[3];
+    if (!alive) *p.done = 1;
+    *p.pos = t + 1;
+  }
+}
+
+__global__ void beam_finalize_kernel(const float* cumul, const int* n_elem, int* order, float* score, int n_img,
+                                     int k) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_img) return;
+  float sc[MAX_K];
+  for (int j = 0; j < k; ++j) { sc[j] = cumul[b * k + j] / (float)n_elem[b * k + j]; score[b * k + j] = sc[j]; }
+  for (int r = 0; r < k; ++r) {
+    int bi = 0; float bv = -INFINITY;
+    for (int j = 0; j < k; ++j) if (sc[j] > bv) { bv = sc[j]; bi = j; }
+    sc[bi] = -INFINITY;
+    order[b * k + r] = bi;
+  }
+}
+
+}  // namespace
+
+extern "C" int odic_dec_embed(const int64_t* tokens, const float* embed, const float* pos_table,
+                              const int32_t* pos, float* y, int64_t ldy, int32_t N, int32_t d, float scale,
+                              void* stream) {
+  if (!tokens || !embed || !pos_table || !pos || !y) return ODIC_ENULL;
+  if (N <= 0 || d <= 0) return ODIC_EINVAL;
+  hipLaunchKernelGGL(dec_embed_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const long long*)tokens, embed,
+                     pos_table, pos, y, (long)ldy, N, d, scale);
+  return odic_launch_status();
+}
+
+extern "C" int odic_dynexp_step(const float* lin, int64_t ldlin, const float* qexp, const float* bexp,
+                                float* cond_c, float* key_c, float* va_c, float* vb_c, float* afull_c,
+                                float* bfull_c, float* qk_c, const int32_t* anc, const int32_t* row_valid,
+                                const int32_t* pos, const float* y_in, int64_t ldy_in, float* y, int64_t ldy,
+                                int32_t N, int32_t T, int32_t d, int32_t E, float eps, void* stream) {
+  if (!lin || !qexp || !bexp || !cond_c || !key_c || !va_c || !vb_c || !afull_c || !bfull_c || !qk_c || !anc ||
+      !row_valid || !pos || !y || !y_in)
+    return ODIC_ENULL;
+  if (N <= 0 || T <= 0 || T > MAX_T || d <= 0 || E <= 0 || E > MAX_E) return ODIC_EINVAL;
+  DynParams p;
+  p.lin = lin; p.ldlin = ldlin; p.qexp = qexp; p.bexp = bexp; p.cond_c = cond_c; p.key_c = key_c; p.va_c = va_c;
+  p.vb_c = vb_c; p.afull_c = afull_c; p.bfull_c = bfull_c; p.qk_c = qk_c; p.anc = anc; p.row_valid = row_valid;
+  p.pos = pos; p.y_in = y_in; p.ldyi = ldy_in; p.y = y; p.ldy = ldy; p.N = N; p.T = T; p.d = d; p.E = E; p.eps = eps;
+  const size_t shmem = (size_t)(2 * d + 2 * MAX_T + MAX_E + 2 * MAX_E + 8) * sizeof(float) + MAX_T * sizeof(int);
+  hipLaunchKernelGGL(dynexp_step_kernel, dim3(N), dim3(256), shmem, (hipStream_t)stream, p);
+  return odic_launch_status();
+}
+
+extern "C" int odic_cross_attn_step(const float* q, int64_t ldq, const float* kv, int64_t ldkv, int32_t koff,
+                                    int32_t voff, const int32_t* enc_len, const int32_t* row_valid, float* out,
+                                    int64_t ldo, int32_t N, int32_t n_img, int32_t S, int32_t d, int32_t heads,
+                                    void* stream) {
+  if (!q || !kv || !enc_len || !row_valid || !out) return ODIC_ENULL;
+  if (N <= 0 || n_img <= 0 || N % n_img || S <= 0 || d <= 0 || heads <= 0 || d % heads || d % 64) return ODIC_EINVAL;
+  const int dk = d / heads, per = d / 64;
+  if (dk % per) return ODIC_EINVAL;
+  const int lph = dk / per;
+  if (lph & (lph - 1)) return ODIC_EINVAL;            // xor-shuffle reduction needs a power of two
+  const size_t shmem = (size_t)(d + heads * S) * sizeof(float);
+  if (shmem > 64 * 1024) return ODIC_EINVAL;
+  hipLaunchKernelGGL(cross_attn_step_kernel, dim3(N), dim3(256), shmem, (hipStream_t)stream, q, (long)ldq, kv,
+                     (long)ldkv, koff, voff, enc_len, row_valid, out, (long)ldo, N / n_img, S, d, heads);
+  return odic_launch_status();
+}
+
+extern "C" int odic_logsoftmax_topk(const float* logits, int64_t ldl, float* logp_out, int64_t ldp, float* top_val,
+                                    int32_t* top_idx, int32_t N, int32_t V, int32_t k, void* stream) {
+  if (!logits || !top_val || !top_idx) return ODIC_ENULL;
+  if (N <= 0 || V <= 0 || k <= 0 || k > MAX_K || k > V) return ODIC_EINVAL;
+  hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, logp_out,
+                     (long)ldp, top_val, top_idx, V, k);
+  return odic_launch_status();
+}
+
+extern "C" int odic_beam_step(const float* cand_val, const int32_t* cand_idx, const odic_beam_state* st,
+                              int32_t n_img, int32_t beams, int32_t T, int64_t eos_idx, void* stream) {
+  if (!cand_val || !cand_idx || !st) return ODIC_ENULL;
+  if (n_img <= 0 || beams <= 0 || beams > MAX_K || T <= 1) return ODIC_EINVAL;
+  if (!st->tokens || !st->logprobs || !st->anc || !st->cumul || !st->n_elem || !st->has_eos || !st->row_valid ||
+      !st->next_tok || !st->pos || !st->done)
+    return ODIC_ENULL;
+  BeamParams p;
+  p.cand_val = cand_val; p.cand_idx = cand_idx;
+  p.tok = (long long*)st->tokens; p.lp = st->logprobs; p.anc = st->anc;
+  p.cumul = st->cumul; p.n_elem = st->n_elem; p.has_eos = st->has_eos; p.row_valid = st->row_valid;
+  p.next_tok = (long long*)st->next_tok; p.pos = st->pos; p.done = st->done;
+  p.n_img = n_img; p.k = beams; p.T = T; p.eos = eos_idx;
+  hipLaunchKernelGGL(beam_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
+  return odic_launch_status();
+}
+
+extern "C" int odic_beam_finalize(const odic_beam_state* st, int32_t* order, float* score, int32_t n_img,
+                                  int32_t beams, void* stream) {
+  if (!st || !order || !score) return ODIC_ENULL;
+  if (n_img <= 0 || beams <= 0 || beams > MAX_K) return ODIC_EINVAL;
+  hipLaunchKernelGGL(beam_finalize_kernel, dim3((n_img + 63) / 64), dim3(64), 0, (hipStream_t)stream, st->cumul,
+                     st->n_elem, order, score, n_img, beams);
+  return odic_launch_status();
+}

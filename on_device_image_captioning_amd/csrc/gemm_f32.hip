@@ -1,0 +1,141 @@
+// fp32 NT GEMM with fused epilogue for gfx950:  out = act(alpha·A·Wᵀ + bias) + residual
+//
+// Exact-fp32 path (parity mode, expansion encoder, decoder): v_mfma_f32_16x16x4_f32 is bit-for-bit
+// a K-ordered fp32 fma chain (no TF32-like truncation exists on gfx950), so results differ from a
+// CPU sgemm only by summation order.
+//
+//   * 64x64x16 block tile, 256 threads = 4 waves (2x2), each wave 32x32 = 2x2 MFMA tiles.
+//   * register-staged double buffering: the loads of K-tile t+1 are issued before the MFMAs of
+//     tile t and written to the other LDS buffer after them (cdna_hip_programming.md T14).
+//   * LDS rows padded to 17 floats: the fragment read A[row=lane&15][k=lane>>4] is conflict-free.
+//   * any M, N, K: out-of-range rows/cols/k are zero-filled; 16-byte loads when lda, ldw, K are
+//     multiples of 4 and the bases are aligned, scalar loads otherwise.
+#include "odic_common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 16, LDP = BK + 1;
+
+struct Params {
+  const float* A; const float* W; const float* bias; const float* residual; void* out;
+  int M, N, K;
+  long lda, ldw, ldr, ldc;
+  long strideA, strideW, strideBias, strideR, strideC;
+  float alpha; int act; int bias_axis; int vec_ok;
+};
+
+__device__ __forceinline__ float4 load4(const float* base, long ld, int row, int nrows, int k, int K,
+                                        bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < nrows) {
+    const float* p = base + (long)row * ld + k;
+    if (vec && k + 3 < K) {
+      v = *(const float4*)p;
+    } else {
+      if (k + 0 < K) v.x = p[0];
+      if (k + 1 < K) v.y = p[1];
+      if (k + 2 < K) v.z = p[2];
+      if (k + 3 < K) v.w = p[3];
+    }
+  }
+  return v;
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void gemm_f32_nt_kernel(Params p) {
+  __shared__ float As[2][BM][LDP];
+  __shared__ float Ws[2][BN][LDP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const long bz = blockIdx.z;
+  const float* A = p.A + bz * p.strideA;
+  const float* W = p.W + bz * p.strideW;
+  const bool vec = p.vec_ok != 0;
+
+  const int lrow = tid >> 2, lk = (tid & 3) * 4;      // this thread stages row lrow, k lk..lk+3
+  const int nk = (p.K + BK - 1) / BK;
+
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  float4 ra = load4(A, p.lda, m0 + lrow, p.M, lk, p.K, vec);
+  float4 rw = load4(W, p.ldw, n0 + lrow, p.N, lk, p.K, vec);
+  As[0][lrow][lk + 0] = ra.x; As[0][lrow][lk + 1] = ra.y; As[0][lrow][lk + 2] = ra.z; As[0][lrow][lk + 3] = ra.w;
+  Ws[0][lrow][lk + 0] = rw.x; Ws[0][lrow][lk + 1] = rw.y; Ws[0][lrow][lk + 2] = rw.z; Ws[0][lrow][lk + 3] = rw.w;
+  __syncthreads();
+
+  const int frow = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      ra = load4(A, p.lda, m0 + lrow, p.M, (kt + 1) * BK + lk, p.K, vec);
+      rw = load4(W, p.ldw, n0 + lrow, p.N, (kt + 1) * BK + lk, p.K, vec);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float a[2], w[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = As[cur][wm * 32 + mi * 16 + frow][ks * 4 + fq];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) w[ni] = Ws[cur][wn * 32 + ni * 16 + frow][ks * 4 + fq];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], w[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      const int nx = cur ^ 1;
+      As[nx][lrow][lk + 0] = ra.x; As[nx][lrow][lk + 1] = ra.y; As[nx][lrow][lk + 2] = ra.z; As[nx][lrow][lk + 3] = ra.w;
+      Ws[nx][lrow][lk + 0] = rw.x; Ws[nx][lrow][lk + 1] = rw.y; Ws[nx][lrow][lk + 2] = rw.z; Ws[nx][lrow][lk + 3] = rw.w;
+    }
+    __syncthreads();
+  }
+
+  const float* bias = p.bias ? p.bias + bz * p.strideBias : nullptr;
+  const float* resid = p.residual ? p.residual + bz * p.strideR : nullptr;
+  OutT* out = (OutT*)p.out + bz * p.strideC;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = m0 + wm * 32 + mi * 16 + fq * 4 + j;
+      if (row >= p.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = n0 + wn * 32 + ni * 16 + frow;
+        if (col >= p.N) continue;
+        float v = acc[mi][ni][j] * p.alpha;
+        if (bias) v += p.bias_axis ? bias[row] : bias[col];
+        v = apply_act<false>(v, p.act);
+        if (resid) v += resid[(long)row * p.ldr + col];
+        store_from_f32<OutT>(out + (long)row * p.ldc + col, v);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int odic_gemm_f32_launch(const odic_gemm_args* a, hipStream_t stream) {
+  Params p;
+  p.A = (const float*)a->A; p.W = (const float*)a->W; p.bias = a->bias; p.residual = a->residual;
+  p.out = a->out; p.M = a->M; p.N = a->N; p.K = a->K;
+  p.lda = a->lda; p.ldw = a->ldw; p.ldr = a->ldr; p.ldc = a->ldc;
+  p.strideA = a->strideA; p.strideW = a->strideW; p.strideBias = a->strideBias;
+  p.strideR = a->strideR; p.strideC = a->strideC;
+  p.alpha = a->alpha; p.act = a->act; p.bias_axis = a->bias_axis;
+  p.vec_ok = (a->lda % 4 == 0) && (a->ldw % 4 == 0) && (a->strideA % 4 == 0) && (a->strideW % 4 == 0) &&
+             (((uintptr_t)a->A & 15) == 0) && (((uintptr_t)a->W & 15) == 0);
+  dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM, a->batch);
+  if (grid.y > 65535) return ODIC_EINVAL;
+  if (a->out_dtype == ODIC_BF16)
+    hipLaunchKernelGGL(gemm_f32_nt_kernel<bf16_raw>, grid, dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL(gemm_f32_nt_kernel<float>, grid, dim3(256), 0, stream, p);
+  return odic_launch_status();
+}

@@ -1,0 +1,315 @@
+// Swin (shifted-)window attention core for gfx950 — SURVEY §8 row A4.
+//
+// One workgroup per (window, head): softmax(q·kᵀ·scale + rel_pos_bias + sw_mask)·v for the N = ws²
+// (= 144) tokens of one window and one 32-wide head.  The cyclic shift, window_partition,
+// window_reverse and reverse shift of the reference (swin_transformer_mod.py:312-334) are pure
+// index maps, so they are folded into the q/k/v gathers and the output scatter: the kernel reads
+// the token-major qkv buffer [B·L, 3C] and writes the token-major attention output [B·L, C].
+// The relative-position index (:163-173) and the SW-MSA mask (:281-297) are recomputed from token
+// coordinates; only the (2ws-1)² x heads bias table is read.
+//
+// Roofline: per (window, head) 2,654,208 FLOP against 36,864 B (bf16) / 73,728 B (fp32) of
+// compulsory q,k,v,out traffic → AI 72 / 36 FLOP/B, far left of the ridge: HBM-bound.
+//
+//   bf16 kernel  3 waves; wave w owns query tiles 3w..3w+2 (48 queries).  Sᵀ = K·Qᵀ by
+//                v_mfma_f32_16x16x32_bf16 (head dim 32 = exactly one MFMA per 16x16 score tile),
+//                so each lane holds, for ITS query (lane&15), keys 16kt+4(lane>>4)+{0..3} of all 9
+//                key tiles: the row softmax is 36 in-register values + 2 shuffle steps.  Those
+//                registers are already the B operand of Oᵀ = Vᵀ·Pᵀ (K index = key, permuted
+//                consistently on both operands), so P never touches LDS.  K is staged row-major,
+//                V transposed ([d][key], zero-padded to 160 keys) in LDS; Q goes straight from
+//                global memory into MFMA fragments.
+//   fp32 kernel  parity path: one thread per query row, K/V fp32 in LDS (broadcast reads), scores
+//                recomputed in two passes (max, then exp/sum/PV) — plain fp32 FMA chains.
+#include "odic_common.h"
+
+namespace {
+
+constexpr int HD = 32;        // head dim of every Swin-L stage
+constexpr int MAXN = 144;     // ws*ws upper bound
+
+struct WinParams {
+  const void* qkv; const float* table; void* out;
+  int B, res, C, heads, ws, shift, nwin_side;
+  float scale;
+};
+
+// token index (row of the [B*L, *] buffers) of slot n of window (wy, wx) in image b, and the region
+// id of that slot on the shifted grid (0..8; all equal when shift == 0)
+__device__ __forceinline__ void slot_to_token(const WinParams& p, int b, int wy, int wx, int n, long& row,
+                                              int& rid) {
+  const int ny = n / p.ws, nx = n - ny * p.ws;
+  const int sy = wy * p.ws + ny, sx = wx * p.ws + nx;          // coords on the shifted grid
+  int y = sy + p.shift, x = sx + p.shift;                     // roll(-shift): shifted[p] = x[p+shift]
+  if (y >= p.res) y -= p.res;
+  if (x >= p.res) x -= p.res;
+  row = ((long)b * p.res + y) * p.res + x;
+  if (p.shift > 0) {
+    const int ey = sy < p.res - p.ws ? 0 : (sy < p.res - p.shift ? 1 : 2);
+    const int ex = sx < p.res - p.ws ? 0 : (sx < p.res - p.shift ? 1 : 2);
+    rid = ey * 3 + ex;
+  } else {
+    rid = 0;
+  }
+}
+
+// =================================================================================================
+// fp32 parity kernel
+// =================================================================================================
+__global__ __launch_bounds__(192) void window_attention_f32_kernel(WinParams p) {
+  __shared__ __attribute__((aligned(16))) float Ks[MAXN][HD];
+  __shared__ __attribute__((aligned(16))) float Vs[MAXN][HD];
+  __shared__ float tab[23 * 23];
+  __shared__ int rids[MAXN];
+  __shared__ long rows[MAXN];
+
+  const int N = p.ws * p.ws;
+  const int head = blockIdx.y;
+  const int win = blockIdx.x;
+  const int wpi = p.nwin_side * p.nwin_side;
+  const int b = win / wpi, wrem = win - b * wpi;
+  const int wy = wrem / p.nwin_side, wx = wrem - wy * p.nwin_side;
+  const int tid = threadIdx.x;
+  const float* qkv = (const float*)p.qkv;
+  const int ld = 3 * p.C;
+  const int ntab = (2 * p.ws - 1) * (2 * p.ws - 1);
+
+  for (int i = tid; i < ntab; i += blockDim.x) tab[i] = p.table[(long)i * p.heads + head];
+  if (tid < N) {
+    long r; int rid;
+    slot_to_token(p, b, wy, wx, tid, r, rid);
+    rows[tid] = r; rids[tid] = rid;
+  }
+  __syncthreads();
+  // stage K and V: N rows x 32 floats = 8 float4 per row
+  for (int i = tid; i < N * 8; i += blockDim.x) {
+    const int n = i >> 3, c = (i & 7) * 4;
+    const float* src = qkv + rows[n] * ld + head * HD + c;
+    *(float4*)&Ks[n][c] = *(const float4*)(src + p.C);
+    *(float4*)&Vs[n][c] = *(const float4*)(src + 2 * p.C);
+  }
+  __syncthreads();
+  if (tid >= N) return;
+
+  float q[HD];
+  {
+    const float* src = qkv + rows[tid] * ld + head * HD;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 t = *(const float4*)(src + c);
+      q[c] = t.x * p.scale; q[c + 1] = t.y * p.scale; q[c + 2] = t.z * p.scale; q[c + 3] = t.w * p.scale;
+    }
+  }
+  const int iy = tid / p.ws, ix = tid - iy * p.ws;
+  const int my_rid = rids[tid];
+  const int tw = 2 * p.ws - 1;
+  const int ibase = (iy + p.ws - 1) * tw + (ix + p.ws - 1);
+
+  auto score = [&](int j, int jy, int jx) -> float {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) s = fmaf(q[c], Ks[j][c], s);
+    s += tab[ibase - jy * tw - jx];
+    if (rids[j] != my_rid) s += -100.0f;
+    return s;
+  };
+
+  float m = -INFINITY;
+  for (int j = 0, jy = 0, jx = 0; j < N; ++j) {
+    m = fmaxf(m, score(j, jy, jx));
+    if (++jx == p.ws) { jx = 0; ++jy; }
+  }
+  float l = 0.f, o[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) o[c] = 0.f;
+  for (int j = 0, jy = 0, jx = 0; j < N; ++j) {
+    const float pj = expf(score(j, jy, jx) - m);
+    l += pj;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) o[c] = fmaf(pj, Vs[j][c], o[c]);
+    if (++jx == p.ws) { jx = 0; ++jy; }
+  }
+  const float inv = 1.0f / l;
+  float* dst = (float*)p.out + rows[tid] * p.C + head * HD;
+#pragma unroll
+  for (int c = 0; c < HD; c += 4)
+    *(float4*)(dst + c) = make_float4(o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv);
+}
+
+// =================================================================================================
+// bf16 MFMA kernel
+// =================================================================================================
+constexpr int VT_LD = 164;    // keys per transposed-V row (160 used + 4 pad → 328-byte rows, 8-B aligned)
+
+__global__ __launch_bounds__(192, 2) void window_attention_bf16_kernel(WinParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_raw Ks[MAXN][HD];       // 9216 B, row-major keys
+  __shared__ __attribute__((aligned(16))) bf16_raw Vt[HD][VT_LD];      // 10496 B, [d][key]
+  __shared__ float tab[23 * 23];
+  __shared__ int rids[MAXN];
+  __shared__ long rows[MAXN];
+
+  const int head = blockIdx.y;
+  const int win = blockIdx.x;
+  const int wpi = p.nwin_side * p.nwin_side;
+  const int b = win / wpi, wrem = win - b * wpi;
+  const int wy = wrem / p.nwin_side, wx = wrem - wy * p.nwin_side;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_raw* qkv = (const bf16_raw*)p.qkv;
+  const int ld = 3 * p.C;
+
+  for (int i = tid; i < 23 * 23; i += 192) tab[i] = p.table[(long)i * p.heads + head];
+  if (tid < MAXN) {
+    long r; int rid;
+    slot_to_token(p, b, wy, wx, tid, r, rid);
+    rows[tid] = r; rids[tid] = rid;
+  }
+  // zero the padded key columns 144..163 of Vᵀ (they meet P = 0, but 0·NaN garbage would poison O)
+  for (int i = tid; i < HD * (VT_LD - MAXN); i += 192) {
+    const int d = i / (VT_LD - MAXN), kk = i - d * (VT_LD - MAXN);
+    Vt[d][MAXN + kk] = 0;
+  }
+  __syncthreads();
+
+  // ---- stage K (row-major) and V (transposed): 144 rows x 4 chunks of 8 bf16
+  for (int i = tid; i < MAXN * 4; i += 192) {
+    const int n = i >> 2, c = (i & 3) * 8;
+    const bf16_raw* src = qkv + rows[n] * ld + head * HD + c;
+    *(bf16x8_t*)&Ks[n][c] = *(const bf16x8_t*)(src + p.C);
+    const bf16x8_t v = *(const bf16x8_t*)(src + 2 * p.C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Vt[c + e][n] = (bf16_raw)v[e];
+  }
+
+  // ---- Q fragments straight from global: B operand of Sᵀ = K·Qᵀ is Q[query = lane&15][d = 8(lane>>4)+j]
+  const int fr = lane & 15, fq = lane >> 4;
+  bf16x8_t qf[3];
+#pragma unroll
+  for (int qt = 0; qt < 3; ++qt) {
+    const int qn = (wave * 3 + qt) * 16 + fr;
+    qf[qt] = *(const bf16x8_t*)(qkv + rows[qn] * ld + head * HD + fq * 8);
+  }
+  __syncthreads();
+
+  // ---- scores: acc[qt][kt][j] = S[query (3w+qt)*16 + fr][key 16kt + 4fq + j]
+  f32x4_t sc[3][9];
+#pragma unroll
+  for (int kt = 0; kt < 9; ++kt) {
+    const bf16x8_t kf = *(const bf16x8_t*)&Ks[kt * 16 + fr][fq * 8];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt)
+      sc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  }
+
+  // ---- scale + relative-position bias + shift mask, row softmax (per query = per lane&15 column)
+  const int tw = 23;
+  float inv_l[3];
+#pragma unroll
+  for (int qt = 0; qt < 3; ++qt) {
+    const int qn = (wave * 3 + qt) * 16 + fr;
+    const int iy = qn / 12, ix = qn - iy * 12;
+    const int ibase = (iy + 11) * tw + (ix + 11);
+    const int my_rid = rids[qn];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kt * 16 + fq * 4 + j;
+        const int jy = key / 12, jx = key - jy * 12;
+        float s = sc[qt][kt][j] * p.scale + tab[ibase - jy * tw - jx];
+        if (rids[key] != my_rid) s += -100.0f;
+        sc[qt][kt][j] = s;
+        m = fmaxf(m, s);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float e = __expf(sc[qt][kt][j] - m);
+        sc[qt][kt][j] = e;
+        l += e;
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    inv_l[qt] = 1.0f / l;
+  }
+
+  // ---- Oᵀ = Vᵀ·Pᵀ : A = Vᵀ[d = 16nt + fr][k-slot], B = Pᵀ[k-slot][query = fr]
+  //      k-slot (fq, e) of K-step s  ↔  key 32s + 16(e>>2) + 4fq + (e&3)   (same map on both operands)
+  f32x4_t oacc[3][2];
+#pragma unroll
+  for (int qt = 0; qt < 3; ++qt) { oacc[qt][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; oacc[qt][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    bf16x8_t vf[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const bf16x4_t lo = *(const bf16x4_t*)&Vt[nt * 16 + fr][32 * s + 4 * fq];
+      const bf16x4_t hi = *(const bf16x4_t*)&Vt[nt * 16 + fr][32 * s + 16 + 4 * fq];
+      vf[nt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) {
+      bf16x8_t pf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pf[e] = (short)f32_to_bf16(sc[qt][2 * s][e]);
+      if (s < 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf[4 + e] = (short)f32_to_bf16(sc[qt][2 * s + 1][e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf[4 + e] = 0;
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        oacc[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[nt], pf, oacc[qt][nt], 0, 0, 0);
+    }
+  }
+
+  // ---- store: lane holds O[query = fr][d = 16nt + 4fq + {0..3}] → 8-byte stores
+  bf16_raw* out = (bf16_raw*)p.out;
+#pragma unroll
+  for (int qt = 0; qt < 3; ++qt) {
+    const int qn = (wave * 3 + qt) * 16 + fr;
+    bf16_raw* dst = out + rows[qn] * p.C + head * HD + fq * 4;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      ushort4 pk;
+      pk.x = f32_to_bf16(oacc[qt][nt][0] * inv_l[qt]);
+      pk.y = f32_to_bf16(oacc[qt][nt][1] * inv_l[qt]);
+      pk.z = f32_to_bf16(oacc[qt][nt][2] * inv_l[qt]);
+      pk.w = f32_to_bf16(oacc[qt][nt][3] * inv_l[qt]);
+      *(ushort4*)(dst + nt * 16) = pk;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int odic_window_attention(const void* qkv, const float* bias_table, void* out, int32_t B,
+                                     int32_t res, int32_t C, int32_t heads, int32_t ws, int32_t shift,
+                                     float scale, int32_t dtype, void* stream) {
+  if (!qkv || !bias_table || !out) return ODIC_ENULL;
+  if (B <= 0 || ws <= 0 || ws * ws > MAXN || res % ws || heads * HD != C || shift < 0 || shift >= ws)
+    return ODIC_EINVAL;
+  if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return ODIC_EINVAL;
+  WinParams p;
+  p.qkv = qkv; p.table = bias_table; p.out = out; p.B = B; p.res = res; p.C = C; p.heads = heads;
+  p.ws = ws; p.shift = shift; p.nwin_side = res / ws; p.scale = scale;
+  dim3 grid(B * p.nwin_side * p.nwin_side, heads), block(192);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == ODIC_F32) {
+    hipLaunchKernelGGL(window_attention_f32_kernel, grid, block, 0, s, p);
+  } else if (dtype == ODIC_BF16) {
+    if (ws != 12) return ODIC_EUNSUPPORTED;      // MFMA tiling is specialised for N = 144
+    hipLaunchKernelGGL(window_attention_bf16_kernel, grid, block, 0, s, p);
+  } else {
+    return ODIC_EINVAL;
+  }
+  return odic_launch_status();
+}

@@ -1,0 +1,200 @@
+"""Thin torch-tensor wrappers over the C ABI (include/odic_hip.h).
+
+PyTorch is plumbing here: tensors own device memory and the current stream; every function hands
+`data_ptr()`s and sizes to libodic_hip.so.  Nothing in this module computes on the CPU and nothing
+falls back — a non-CUDA tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _hip
+from ._hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F32  # noqa: F401  (re-exported)
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts: Optional[torch.Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("odic ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {dt}") from None
+
+
+# ----------------------------------------------------------------------------------------------
+def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
+         alpha: float = 1.0, bias_axis: int = 0, out_dtype: Optional[torch.dtype] = None,
+         M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None,
+         lda: Optional[int] = None, ldw: Optional[int] = None, ldr: Optional[int] = None,
+         ldc: Optional[int] = None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideBias: int = 0,
+         strideR: int = 0, strideC: int = 0) -> torch.Tensor:
+    """out = act(alpha·A·Wᵀ + bias) + residual.  With no explicit dims, A is [..., K] (flattened to
+    [M,K]) and W is [N,K], both contiguous.  Explicit dims / leading dimensions / batch strides allow
+    strided sub-matrices (elements)."""
+    _need_cuda(A, W, bias, residual, out)
+    if A.dtype != W.dtype:
+        raise RuntimeError("A and W must share a dtype")
+    if M is None:
+        K = A.shape[-1]
+        M = A.numel() // K
+        N = W.shape[0]
+        lda, ldw = K, W.shape[-1]
+        if not (A.is_contiguous() and W.is_contiguous()):
+            raise RuntimeError("gemm: implicit-shape operands must be contiguous")
+    odt = out_dtype or (out.dtype if out is not None else A.dtype)
+    if out is None:
+        out = torch.empty((batch, M, N) if batch > 1 else (*A.shape[:-1], N), dtype=odt, device=A.device)
+        if ldc is None:
+            ldc = N
+        if batch > 1 and strideC == 0:
+            strideC = M * N
+    if ldc is None:
+        ldc = N
+    if residual is not None and ldr is None:
+        ldr = N
+    if bias is not None and bias.dtype != torch.float32:
+        raise RuntimeError("bias must be fp32")
+    if residual is not None and residual.dtype != torch.float32:
+        raise RuntimeError("residual must be fp32")
+    a = _hip.GemmArgs(_p(A), _p(W), _p(bias), _p(residual), _p(out), M, N, K, lda, ldw, ldr or 0, ldc, batch,
+                      strideA, strideW, strideBias, strideR, strideC, alpha, act, bias_axis,
+                      dtype_code(A.dtype), dtype_code(out.dtype))
+    _hip.check(_hip.load().odic_gemm(C.byref(a), _stream()), "odic_gemm")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, eps: float = 1e-5,
+              out_dtype: torch.dtype = torch.float32, out: Optional[torch.Tensor] = None,
+              M: Optional[int] = None, C_: Optional[int] = None, ldx: Optional[int] = None) -> torch.Tensor:
+    _need_cuda(x, gamma, beta, out)
+    if M is None:
+        C_ = x.shape[-1]
+        M = x.numel() // C_
+        ldx = C_
+        if not x.is_contiguous():
+            raise RuntimeError("layernorm: implicit-shape input must be contiguous")
+    if out is None:
+        out = torch.empty((M, C_) if x.dim() < 2 or ldx != C_ else x.shape, dtype=out_dtype, device=x.device)
+    _hip.check(_hip.load().odic_layernorm(_p(x), ldx, _p(gamma), _p(beta), _p(out), M, C_, eps,
+                                          dtype_code(out.dtype), _stream()), "odic_layernorm")
+    return out
+
+
+def patch_merge_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, res: int, Cin: int,
+                          *, eps: float = 1e-5, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    _need_cuda(x, gamma, beta)
+    out = torch.empty((B, (res // 2) ** 2, 4 * Cin), dtype=out_dtype, device=x.device)
+    _hip.check(_hip.load().odic_patch_merge_layernorm(_p(x), _p(gamma), _p(beta), _p(out), B, res, Cin, eps,
+                                                      dtype_code(out_dtype), _stream()),
+               "odic_patch_merge_layernorm")
+    return out
+
+
+def patch_embed(img: torch.Tensor, w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                patch: int, *, eps: float = 1e-5) -> torch.Tensor:
+    _need_cuda(img, w, b, gamma, beta)
+    B, Cin, H, Wd = img.shape
+    Cout = w.shape[0]
+    if not img.is_contiguous() or img.dtype != torch.float32:
+        raise RuntimeError("patch_embed: image batch must be contiguous fp32 [B,C,H,W]")
+    out = torch.empty((B, (H // patch) * (Wd // patch), Cout), dtype=torch.float32, device=img.device)
+    _hip.check(_hip.load().odic_patch_embed(_p(img), _p(w), _p(b), _p(gamma), _p(beta), _p(out), B, Cin, H, Wd,
+                                            patch, Cout, eps, _stream()), "odic_patch_embed")
+    return out
+
+
+def window_attention(qkv: torch.Tensor, bias_table: torch.Tensor, B: int, res: int, C_: int, heads: int, ws: int,
+                     shift: int, *, scale: Optional[float] = None, out: Optional[torch.Tensor] = None
+                     ) -> torch.Tensor:
+    _need_cuda(qkv, bias_table, out)
+    if scale is None:
+        scale = (C_ // heads) ** -0.5
+    if out is None:
+        out = torch.empty((B * res * res, C_), dtype=qkv.dtype, device=qkv.device)
+    _hip.check(_hip.load().odic_window_attention(_p(qkv), _p(bias_table), _p(out), B, res, C_, heads, ws, shift,
+                                                 scale, dtype_code(qkv.dtype), _stream()),
+               "odic_window_attention")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+def stcexp_group_meta(groups: Sequence[int], device) -> torch.Tensor:
+    starts = [0]
+    gid = []
+    for g, n in enumerate(groups):
+        starts.append(starts[-1] + n)
+        gid += [g] * n
+    return torch.tensor(starts + gid, dtype=torch.int32, device=device)
+
+
+def stcexp_normalize(z: torch.Tensor, enc_len: torch.Tensor, group_meta: torch.Tensor, ngroups: int,
+                     pos_fw: torch.Tensor, neg_fw: torch.Tensor, pos_bw: torch.Tensor, neg_bw: torch.Tensor,
+                     colsum_ws: torch.Tensor, *, eps: float = 1e-9) -> None:
+    _need_cuda(z, enc_len, group_meta, pos_fw, neg_fw, pos_bw, neg_bw, colsum_ws)
+    B, nq, S = z.shape
+    _hip.check(_hip.load().odic_stcexp_normalize(_p(z), _p(enc_len), _p(group_meta), ngroups, _p(pos_fw),
+                                                 _p(neg_fw), _p(pos_bw), _p(neg_bw), _p(colsum_ws), B, nq, S, eps,
+                                                 _stream()), "odic_stcexp_normalize")
+
+
+def selector_mix(x, ldx, sel_pre, lds, a, lda, b, ldb, out, ldo, M, d) -> None:
+    _need_cuda(x, sel_pre, a, b, out)
+    _hip.check(_hip.load().odic_selector_mix(_p(x), ldx, _p(sel_pre), lds, _p(a), lda, _p(b), ldb, _p(out), ldo,
+                                             M, d, _stream()), "odic_selector_mix")
+
+
+# ----------------------------------------------------------------------------------------------
+def dec_embed(tokens, embed, pos_table, pos, y, ldy, N, d, scale) -> None:
+    _need_cuda(tokens, embed, pos_table, pos, y)
+    _hip.check(_hip.load().odic_dec_embed(_p(tokens), _p(embed), _p(pos_table), _p(pos), _p(y), ldy, N, d, scale,
+                                          _stream()), "odic_dec_embed")
+
+
+def dynexp_step(lin, ldlin, qexp, bexp, cond_c, key_c, va_c, vb_c, afull_c, bfull_c, qk_c, anc, row_valid, pos,
+                y_in, ldy_in, y, ldy, N, T, d, E, eps=1e-9) -> None:
+    _need_cuda(lin, qexp, bexp, cond_c, key_c, va_c, vb_c, afull_c, bfull_c, qk_c, anc, row_valid, pos, y_in, y)
+    _hip.check(_hip.load().odic_dynexp_step(_p(lin), ldlin, _p(qexp), _p(bexp), _p(cond_c), _p(key_c), _p(va_c),
+                                            _p(vb_c), _p(afull_c), _p(bfull_c), _p(qk_c), _p(anc), _p(row_valid),
+                                            _p(pos), _p(y_in), ldy_in, _p(y), ldy, N, T, d, E, eps, _stream()),
+               "odic_dynexp_step")
+
+
+def cross_attn_step(q, ldq, kv, ldkv, koff, voff, enc_len, row_valid, out, ldo, N, n_img, S, d, heads) -> None:
+    _need_cuda(q, kv, enc_len, row_valid, out)
+    _hip.check(_hip.load().odic_cross_attn_step(_p(q), ldq, _p(kv), ldkv, koff, voff, _p(enc_len), _p(row_valid),
+                                                _p(out), ldo, N, n_img, S, d, heads, _stream()),
+               "odic_cross_attn_step")
+
+
+def logsoftmax_topk(logits, ldl, logp_out, ldp, top_val, top_idx, N, V, k) -> None:
+    _need_cuda(logits, logp_out, top_val, top_idx)
+    _hip.check(_hip.load().odic_logsoftmax_topk(_p(logits), ldl, _p(logp_out), ldp, _p(top_val), _p(top_idx), N, V,
+                                                k, _stream()), "odic_logsoftmax_topk")
+
+
+def beam_step(cand_val, cand_idx, state: "_hip.BeamState", n_img, beams, T, eos_idx) -> None:
+    _hip.check(_hip.load().odic_beam_step(_p(cand_val), _p(cand_idx), C.byref(state), n_img, beams, T, eos_idx,
+                                          _stream()), "odic_beam_step")
+
+
+def beam_finalize(state: "_hip.BeamState", order, score, n_img, beams) -> None:
+    _hip.check(_hip.load().odic_beam_finalize(C.byref(state), _p(order), _p(score), n_img, beams, _stream()),
+               "odic_beam_finalize")

@@ -1,0 +1,275 @@
+"""Per-kernel parity: every C-ABI entry point against the CPU oracle / plain fp32 torch formulas.
+
+`-m gpu` only.  Tolerances: fp32 kernels 2e-5 relative to the output scale (summation order only);
+bf16 kernels are compared against an fp64 evaluation of the SAME bf16-rounded inputs, so the
+tolerance covers accumulation order + the final bf16 rounding (2^-8 relative).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from on_device_image_captioning_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from on_device_image_captioning_amd import _hip, ops as o
+    _hip.load()          # fail loudly if the extension is missing
+    return o
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def assert_close(got, want, rtol, name=""):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    scale = want.abs().max().item() + 1e-12
+    err = (got - want).abs().max().item()
+    assert err <= rtol * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e} (rtol {rtol})"
+
+
+# ------------------------------------------------------------------------------------------ GEMM fp32
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (48, 512, 512), (300, 190, 52), (144, 1000, 37), (1, 10, 3),
+                                   (2304, 512, 1536)])
+def test_gemm_f32_shapes(ops, M, N, K):
+    A, Wt, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    want = A.double() @ Wt.double().T + b.double()
+    got = ops.gemm(dev(A), dev(Wt), dev(b))
+    assert_close(got, want, 2e-5, "gemm_f32")
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_gemm_f32_epilogues(ops, act):
+    M, N, K = 130, 96, 64
+    A, Wt, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    pre = 0.5 * (A.double() @ Wt.double().T) + b.double()
+    f = [lambda v: v, lambda v: torch.nn.functional.gelu(v), torch.relu, torch.sigmoid][act]
+    want = f(pre) + r.double()
+    got = ops.gemm(dev(A), dev(Wt), dev(b), dev(r), act=act, alpha=0.5)
+    assert_close(got, want, 2e-5, f"gemm_f32 act{act}")
+
+
+def test_gemm_f32_row_bias_strided_batched(ops):
+    # out[b] = A · W[b]ᵀ + bias[m]  with A shared, W a strided sub-matrix, padded output rows
+    Bn, M, N, K, ldw, ldc = 3, 70, 50, 40, 100, 64
+    A, Wfull, bias = rnd(M, K, seed=1), rnd(Bn, N, ldw, seed=2), rnd(M, seed=3)
+    out = torch.full((Bn, M, ldc), 7.0)
+    dout = dev(out)
+    ops.gemm(dev(A), dev(Wfull)[:, :, 8:], dev(bias), out=dout, bias_axis=1, M=M, N=N, K=K, lda=K, ldw=ldw,
+             ldc=ldc, batch=Bn, strideA=0, strideW=N * ldw, strideC=M * ldc)
+    # note: the W view starts 8 columns in → pointer offset handled by passing a view's data_ptr
+    want = torch.einsum("mk,bnk->bmn", A.double(), Wfull[:, :, 8:8 + K].double()) + bias.double()[None, :, None]
+    got = dout.cpu()
+    assert_close(got[:, :, :N], want, 2e-5, "gemm_f32 batched")
+    assert torch.all(got[:, :, N:] == 7.0), "padding columns must stay untouched"
+
+
+# ------------------------------------------------------------------------------------------ GEMM bf16
+def test_gemm_bf16_identity_asymmetric(ops):
+    # A = I, asymmetric small-integer W: out must equal Wᵀ exactly (catches any fragment / C-layout swap)
+    K = 128
+    A = torch.eye(K)
+    Wt = (torch.arange(192 * K).reshape(192, K) % 251 - 125).float()
+    got = ops.gemm(dev(A).bfloat16(), dev(Wt).bfloat16(), out_dtype=torch.float32)
+    assert torch.equal(got.cpu(), Wt.T.contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 192, 192), (144, 576, 192), (2304, 1536, 6144),
+                                   (1000, 3072, 768)])
+def test_gemm_bf16_random(ops, M, N, K):
+    A, Wt, b, r = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=0.05).bfloat16(), rnd(N, seed=3), rnd(M, N, seed=4)
+    want = A.double() @ Wt.double().T + b.double()
+    got32 = ops.gemm(dev(A), dev(Wt), dev(b), dev(r), out_dtype=torch.float32)
+    assert_close(got32, want + r.double(), 2e-4, "gemm_bf16→f32")
+    got16 = ops.gemm(dev(A), dev(Wt), dev(b), act=1, out_dtype=torch.bfloat16)
+    assert_close(got16, torch.nn.functional.gelu(want), 6e-3, "gemm_bf16 gelu→bf16")
+
+
+# ------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("C", [96, 192, 512, 768, 1536, 3072, 6144])
+@pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
+def test_layernorm(ops, C, odt):
+    M = 37
+    x, g, b = rnd(M, C, seed=1, scale=3.0) + 0.7, 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    want = torch.nn.functional.layer_norm(x.double(), (C,), g.double(), b.double(), 1e-5)
+    got = ops.layernorm(dev(x), dev(g), dev(b), out_dtype=odt)
+    assert got.dtype == odt
+    assert_close(got, want, 2e-5 if odt == torch.float32 else 5e-3, "layernorm")
+
+
+def test_patch_merge_layernorm(ops):
+    from oracle import expansionnet_ref as R
+    B, res, C = 2, 24, 96
+    x = rnd(B, res * res, C, seed=5)
+    g, b = 1 + 0.1 * rnd(4 * C, seed=2), 0.1 * rnd(4 * C, seed=3)
+    sd = {"m.norm.weight": g, "m.norm.bias": b, "m.reduction.weight": torch.eye(4 * C)}
+    want = R.patch_merging(sd, "m", x, res)            # identity reduction → exposes gather + LN
+    got = ops.patch_merge_layernorm(dev(x), dev(g), dev(b), B, res, C)
+    assert_close(got, want, 2e-5, "patch_merge_ln")
+
+
+def test_patch_embed(ops):
+    from oracle import expansionnet_ref as R
+    g = W.TINY
+    sd = {k: W.synth_tensor(k, s, kind, g) for k, s, kind in W.state_dict_spec(g) if "patch_embed" in k}
+    img = W.synth_images(2, g)
+    want = R.patch_embed(sd, g, img)
+    P = "swin_transf.patch_embed"
+    got = ops.patch_embed(dev(img), dev(sd[P + ".proj.weight"].reshape(g.swin_embed_dim, -1).contiguous()),
+                          dev(sd[P + ".proj.bias"]), dev(sd[P + ".norm.weight"]), dev(sd[P + ".norm.bias"]), 4)
+    assert_close(got, want, 2e-5, "patch_embed")
+
+
+# ------------------------------------------------------------------------------------------ window attention
+def _win_ref(qkv, table, B, res, C, heads, ws, shift):
+    from oracle import expansionnet_ref as R
+    tok = R.window_token_index(res, ws, shift)
+    nW, N = tok.shape
+    x = qkv.view(B, res * res, 3, heads, 32)[:, tok.reshape(-1)].view(B, nW, N, 3, heads, 32)
+    q, k, v = (x[:, :, :, i].permute(0, 1, 3, 2, 4) for i in range(3))
+    idx = W.relative_position_index(ws)
+    bias = table[idx.reshape(-1)].reshape(N, N, heads).permute(2, 0, 1)
+    mask = W.shifted_window_attn_mask(res, ws, shift) if shift > 0 else None
+    o = R.window_attention_core(q.double(), k.double(), v.double(), bias.double(),
+                                None if mask is None else mask.double(), 32 ** -0.5)
+    o = o.permute(0, 1, 3, 2, 4).reshape(B, nW * N, C)
+    out = torch.empty(B, res * res, C, dtype=torch.float64)
+    out[:, tok.reshape(-1)] = o
+    return out.reshape(B * res * res, C)
+
+
+@pytest.mark.parametrize("res,heads,shift", [(96, 3, 0), (96, 3, 6), (48, 6, 6), (24, 12, 6), (24, 12, 0), (12, 48, 0)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_window_attention(ops, res, heads, shift, dt):
+    B, ws = 2, 12
+    C = heads * 32
+    qkv = rnd(B * res * res, 3 * C, seed=res + shift, scale=1.5).to(dt)
+    table = rnd(529, heads, seed=9, scale=0.5)
+    want = _win_ref(qkv.float(), table, B, res, C, heads, ws, shift)
+    got = ops.window_attention(dev(qkv), dev(table), B, res, C, heads, ws, shift)
+    assert got.dtype == dt
+    assert_close(got, want, 2e-5 if dt == torch.float32 else 1.2e-2, f"window_attention {dt}")
+
+
+# ------------------------------------------------------------------------------------------ encoder glue
+def test_stcexp_normalize_and_mix(ops):
+    B, S, groups = 3, 20, (8, 16, 24)
+    nq = sum(groups)
+    z = rnd(B, nq, S, seed=3)
+    lens = torch.tensor([20, 13, 17], dtype=torch.int32)
+    valid = (torch.arange(S)[None, :] < lens[:, None]).double()[:, None, :]
+    zd = z.double()
+    pf, nf = torch.relu(zd) * valid, torch.relu(-zd) * valid
+    pf, nf = pf / (pf.sum(-1, keepdim=True) + 1e-9), nf / (nf.sum(-1, keepdim=True) + 1e-9)
+    zt = zd.transpose(1, 2)
+    pb, nb = torch.relu(zt).clone(), torch.relu(-zt).clone()
+    lo = 0
+    for n in groups:
+        pb[..., lo:lo + n] = pb[..., lo:lo + n] / (pb[..., lo:lo + n].sum(-1, keepdim=True) + 1e-9)
+        nb[..., lo:lo + n] = nb[..., lo:lo + n] / (nb[..., lo:lo + n].sum(-1, keepdim=True) + 1e-9)
+        lo += n
+    d = "cuda"
+    o = [torch.empty(B, nq, S, device=d), torch.empty(B, nq, S, device=d), torch.empty(B, S, nq, device=d),
+         torch.empty(B, S, nq, device=d)]
+    ws = torch.empty(B * len(groups) * 2 * S, device=d)
+    ops.stcexp_normalize(dev(z), dev(lens), ops.stcexp_group_meta(groups, d), len(groups), *o, ws)
+    assert_close(o[0], pf, 2e-5, "pos_fw"); assert_close(o[1], nf, 2e-5, "neg_fw")
+    assert_close(o[2], pb / len(groups), 2e-5, "pos_bw"); assert_close(o[3], nb / len(groups), 2e-5, "neg_bw")
+    M, dm = 50, 128
+    x, s, a, b = (rnd(M, dm, seed=i) for i in range(4))
+    out = torch.empty(M, dm, device=d)
+    ops.selector_mix(dev(x), dm, dev(s), dm, dev(a), dm, dev(b), dm, out, dm, M, dm)
+    sg = torch.sigmoid(s.double())
+    assert_close(out, x.double() + sg * a.double() + (1 - sg) * b.double(), 2e-5, "selector_mix")
+
+
+# ------------------------------------------------------------------------------------------ decoder steps
+def test_logsoftmax_topk(ops):
+    N, V, k = 7, 10000, 5
+    x = rnd(N, V, seed=1, scale=3.0)
+    want = torch.log_softmax(x.double(), -1)
+    wv, wi = torch.topk(want, k, -1)
+    lp = torch.empty(N, V, device="cuda")
+    tv = torch.empty(N, k, device="cuda")
+    ti = torch.empty(N, k, dtype=torch.int32, device="cuda")
+    ops.logsoftmax_topk(dev(x), V, lp, V, tv, ti, N, V, k)
+    assert_close(lp, want, 2e-6, "log_softmax")
+    assert torch.equal(ti.cpu().long(), wi)
+    assert_close(tv, wv, 2e-6, "topk values")
+
+
+def test_cross_attn_step(ops):
+    n_img, beams, S, d, heads = 3, 2, 20, 128, 4
+    N = n_img * beams
+    q = rnd(N, d, seed=1)
+    kv = rnd(n_img, S, 3 * d, seed=2)          # K at col 16.. is not contiguous with V on purpose
+    koff, voff = d, 2 * d
+    lens = torch.tensor([20, 11, 16], dtype=torch.int32)
+    valid = torch.tensor([1, 1, 1, 0, 1, 1], dtype=torch.int32)
+    out = torch.empty(N, d, device="cuda")
+    ops.cross_attn_step(dev(q), d, dev(kv), 3 * d, koff, voff, dev(lens), dev(valid), out, d, N, n_img, S, d, heads)
+    dk = d // heads
+    want = torch.empty(N, d, dtype=torch.float64)
+    for n in range(N):
+        i = n // beams
+        K = kv[i, :, koff:koff + d].double().view(S, heads, dk)
+        Vv = kv[i, :, voff:voff + d].double().view(S, heads, dk)
+        s = torch.einsum("hc,shc->hs", q[n].double().view(heads, dk), K) / math.sqrt(dk)
+        allow = (torch.arange(S) < lens[i]) & bool(valid[n])
+        s = s.masked_fill(~allow[None, :], -1e4)
+        want[n] = torch.einsum("hs,shc->hc", torch.softmax(s, -1), Vv).reshape(d)
+    assert_close(out, want, 2e-5, "cross_attn_step")
+
+
+def test_dynexp_step_matches_full_recompute(ops):
+    """Feed T positions one at a time (identity ancestry) and compare every row with the oracle's
+    full-prefix DynamicExpansionBlock."""
+    from oracle import expansionnet_ref as R
+    N, T, d, E = 3, 9, 128, 4
+    names = ["cond_embed", "key_linear", "class_a_embed", "class_b_embed", "selector_embed"]
+    sd = {}
+    for i, nm in enumerate(names):
+        sd[f"p.{nm}.weight"] = rnd(d, d, seed=10 + i, scale=d ** -0.5)
+        sd[f"p.{nm}.bias"] = rnd(d, seed=20 + i, scale=0.1)
+    sd["p.query_exp_vectors.weight"] = rnd(E, d, seed=30, scale=0.3)
+    sd["p.bias_exp_vectors.weight"] = rnd(E, d, seed=31, scale=0.3)
+    x = rnd(N, T, d, seed=40)
+    pads = [0, 2, 4]
+    t = torch.arange(T)
+    ok = t[None, :] < (T - torch.tensor(pads))[:, None]
+    causal = ((t[None, :, None] >= t[None, None, :]) & ok[:, :, None] & ok[:, None, :]).float()
+    want = R.dynamic_expansion(sd, "p", x, E, causal)                     # (N,T,d)
+
+    dv = "cuda"
+    Wcat = torch.cat([sd[f"p.{nm}.weight"] for nm in names], 0)
+    bcat = torch.cat([sd[f"p.{nm}.bias"] for nm in names], 0)
+    caches = [torch.zeros(T, N, d, device=dv) for _ in range(4)] + [torch.zeros(T, N, E, d, device=dv) for _ in range(2)]
+    qk = torch.zeros(T, N, E, device=dv)
+    anc = torch.arange(N, dtype=torch.int32, device=dv)[:, None].repeat(1, T).contiguous()
+    pos = torch.zeros(1, dtype=torch.int32, device=dv)
+    got = torch.empty(N, T, d)
+    for step in range(T):
+        pos.fill_(step)
+        xs = dev(x[:, step].contiguous())
+        lin = ops.gemm(xs, dev(Wcat), dev(bcat))
+        y = torch.zeros(N, d, device=dv)
+        valid = dev(ok[:, step].to(torch.int32))
+        ops.dynexp_step(lin, 5 * d, dev(sd["p.query_exp_vectors.weight"]), dev(sd["p.bias_exp_vectors.weight"]),
+                        *caches, qk, anc, valid, pos, y, d, y, d, N, T, d, E)
+        got[:, step] = y.cpu()
+    assert_close(got, want, 5e-5, "dynexp_step")
