@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — captions/sec of the end-to-end ExpansionNet v2 path on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch on every rank: 16 synthetic 384x384 images →
+Swin-L → expansion encoder → beam-3 search (beam_max_seq_len 20; synthetic xavier weights never emit
+EOS so every caption runs the full 19 decoder steps) → RCCL all_gather of the token ids (N > 1).
+BASELINE.json configs[2]: "End_ExpansionNet_v2 end-to-end with Swin-L 384 backbone, batch 16 bf16,
+beam=3, 1xMI355X".  Inputs are resident in HBM when the timed region starts.  Weak scaling: every
+rank processes its own batch of 16.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      for the dominant kernel family (by time), measured in an extra instrumented pass of
+                the same workload with HIP events on the launch stream (torch.cuda.Event on the
+                current stream = the stream the kernels are launched on)
+  cpu_baseline  the CPU oracle (oracle/expansionnet_ref.py, kind "port") on the host cores, same
+                model, B=1 (the demo.py shape), beam 3, T=20 — a bounded sample, reported not targeted
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}     # MI355X_MICROARCH.md
+SOS, EOS = 79, 77
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--beam", type=int, default=3)
+    ap.add_argument("--max-len", type=int, default=20)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-runs", type=int, default=6)
+    return ap.parse_args()
+
+
+def build_model(device, precision):
+    from on_device_image_captioning_amd import weights as W
+    from on_device_image_captioning_amd.End_ExpansionNet_v2 import End_ExpansionNet_v2, make_drop_args
+    g = W.FULL
+    sd = W.synth_state_dict(g, variant="xavier")
+    m = End_ExpansionNet_v2(**g.model_kwargs(), output_word2idx={i: i for i in range(g.vocab_size)},
+                            output_idx2word=list(range(g.vocab_size)), drop_args=make_drop_args(), rank=device)
+    m.load_state_dict(sd, strict=True)
+    m.to(device).eval().set_precision(precision)
+    return m, sd, g
+
+
+def roofline_pass(pipe, images):
+    """One extra eager pass of the same workload with per-launch HIP events."""
+    from on_device_image_captioning_amd import ops
+    g_enc, g_step = pipe.g_enc, pipe.g_step
+    pipe.g_enc = pipe.g_step = None           # eager launches so that events bracket single kernels
+    try:
+        pipe.enqueue(images)                   # warm
+        torch.cuda.synchronize()
+        with ops.profile() as recs:
+            pipe.enqueue(images)
+        torch.cuda.synchronize()
+    finally:
+        pipe.g_enc, pipe.g_step = g_enc, g_step
+    fam, shapes = {}, {}
+    for name, flops, nbytes, s, e, detail in recs:
+        ms = s.elapsed_time(e)
+        for key, table in ((name, fam), (f"{name}:{detail}", shapes)):
+            d = table.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            d["ms"] += ms
+            d["flops"] += flops
+            d["bytes"] += nbytes
+            d["launches"] += 1
+    if os.environ.get("ODIC_BENCH_SHAPES"):
+        with open(os.environ["ODIC_BENCH_SHAPES"], "w") as f:
+            for key, d in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
+                sec = d["ms"] * 1e-3
+                f.write(f"{key:44s} n={d['launches']:4d} total {d['ms']:8.3f} ms  avg {1e3 * d['ms'] / d['launches']:8.1f} us"
+                        f"  {d['flops'] / sec / 1e12:8.1f} TF/s  {d['bytes'] / sec / 1e9:8.1f} GB/s\n")
+    return fam
+
+
+def roofline_entry(name, d):
+    sec = d["ms"] * 1e-3
+    if name.startswith("gemm") :
+        peak = PEAK["mfma_bf16_tflops"] if name == "gemm_bf16" else PEAK["mfma_f32_tflops"]
+        ach = d["flops"] / sec / 1e12
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None, "launches": d["launches"],
+                "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+                "algorithmic_flops_per_step": d["flops"]}
+    ach = d["bytes"] / sec / 1e9
+    return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK["hbm_gbs"], "unit": "GB/s",
+            "frac": round(ach / PEAK["hbm_gbs"], 4), "traffic": None, "launches": d["launches"],
+            "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2), "algorithmic_bytes_per_step": d["bytes"]}
+
+
+def cpu_baseline(sd, g, runs, beam, max_len):
+    """The oracle in the demo.py shape: one image at a time, fp32, all host cores
+    (timing harness shape of reference benchmarking/benchmarking.py:95-103)."""
+    from on_device_image_captioning_amd import weights as W
+    from oracle import expansionnet_ref as R
+    img = W.synth_images(1, g)
+    with torch.no_grad():
+        R.beam_search(sd, g, img, [0], SOS, EOS, beam, 1, max_len)        # warm-up
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            R.beam_search(sd, g, img, [0], SOS, EOS, beam, 1, max_len)
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{runs} captions, B=1 (demo.py shape), beam {beam}, T={max_len}, fp32, median of {runs}; "
+                      f"mean {sum(ts) / len(ts):.3f}s/caption; os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+
+    from on_device_image_captioning_amd import weights as W
+    from on_device_image_captioning_amd.pipeline import CaptionPipeline, gather_captions
+    torch.set_grad_enabled(False)
+    model, sd, g = build_model(device, a.precision)
+    pipe = CaptionPipeline(model, a.batch, a.beam, a.max_len, SOS, EOS, use_graphs=not a.no_graphs)
+    images = W.synth_images(a.batch, g, seed=42 + rank).to(device)         # resident in HBM
+
+    def step():
+        pipe.enqueue(images)
+        toks, lens = pipe.best_tokens()
+        caps = gather_captions(toks, lens, a.batch * world)      # N>1: RCCL all_gather; always ends on the host
+        return caps, lens
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        caps, lens = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        out = {
+            "metric": "captions/sec end-to-end (Swin-L 384, beam=3) at 1/2/4/8 MI355X",
+            "value": round(a.batch * world * a.steps / dt, 2), "unit": "captions/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.precision if a.precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": "End_ExpansionNet_v2 end-to-end, Swin-L/384 backbone, batch 16 per GPU, "
+                                   "beam 3, beam_max_seq_len 20 (BASELINE.json configs[2])",
+                       "batch_per_gpu": a.batch, "beam": a.beam, "beam_max_seq_len": a.max_len,
+                       "decoder_steps": pipe.steps, "weights": "synthetic xavier (Philox, seed 0)",
+                       "backbone_precision": a.precision, "captioner_precision": "fp32",
+                       "hip_graphs": not a.no_graphs, "parallelism": f"image-shard x{world}",
+                       "caption_len_check": int(lens.min().item())},
+        }
+        if not a.no_roofline:
+            fam = roofline_pass(pipe, images)
+            total_ms = sum(d["ms"] for d in fam.values())
+            entries = sorted((roofline_entry(n, d) for n, d in fam.items()), key=lambda e: -fam[e["kernel"]]["ms"])
+            for e in entries:
+                e["time_share"] = round(fam[e["kernel"]]["ms"] / total_ms, 4)
+            out["roofline"] = entries[0]
+            out["roofline_note"] = ("achieved = algorithmic FLOPs (2·M·N·K per GEMM) or bytes (q,k,v in + o out per "
+                                    "(window, head)) ÷ Σ HIP-event durations of that kernel family in one instrumented "
+                                    "eager pass of the same step; traffic: see profiles/ PMC runs")
+            out["kernels"] = entries
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, g, a.cpu_runs, a.beam, a.max_len)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

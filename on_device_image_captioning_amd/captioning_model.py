@@ -1,0 +1,239 @@
+"""Search / API layer.
+
+Two call shapes of the reference are served:
+  * legacy:      model(enc_x, dec_x, enc_x_num_pads, dec_x_num_pads, apply_log_softmax, mode=..., **kw)
+                 and model.beam_search(...)            — legacy_models/captioning_model.py:24-57,111-241
+                 (what demo.py:124-129 and test.py:209-214 call)
+  * refactored:  Captioner(beam_search_args, model=...)(enc_x, enc_x_num_pads=..., mode="beam_search")
+                                                       — models/captioning_model.py:40-110
+
+The search itself runs on the GPU: one incremental decoder step per new token (engine.py) and the
+beam bookkeeping of captioning_model.py:172-223 in odic_beam_step.  The host loop only enqueues
+steps; it looks at the device-side `done` flag every few steps (the all-beams-finished state is a
+fixed point of the step, so running a few extra steps cannot change the result).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import engine as _engine
+from . import ops
+
+_DONE_POLL = 4      # host looks at the device `done` flag every this many steps
+
+
+class CaptioningModel(nn.Module):
+    """Base class: mode dispatch + GPU search.  Subclasses provide `_engines()`, `forward_enc`,
+    `_cross_kv(mem)` and set `self.rank` (legacy_models/captioning_model.py:11-16)."""
+
+    def __init__(self, apply_log_softmax: bool = False):
+        super().__init__()
+        self.rank = None
+        self.apply_log_softmax = apply_log_softmax
+        self._eng_cache = None
+        self.precision = "fp32"
+
+    # ------------------------------------------------------------------ engine cache plumbing
+    def check_required_attributes(self):
+        if self.rank is None:
+            raise NotImplementedError("Subclass must assign the rank integer according to the GPU group")
+
+    def set_precision(self, precision: str) -> "CaptioningModel":
+        """'fp32' (default; exact-fp32 MFMA, parity mode) or 'bf16' (backbone GEMMs + window
+        attention in bf16 with fp32 accumulation and an fp32 residual stream)."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision != self.precision:
+            self.precision = precision
+            self._eng_cache = None
+        return self
+
+    def _apply(self, fn, *a, **k):
+        self._eng_cache = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._eng_cache = None
+        return super().load_state_dict(*a, **k)
+
+    def _device(self) -> torch.device:
+        dv = next(self.parameters()).device
+        if dv.type != "cuda":
+            raise RuntimeError("the HIP path needs the model on a GPU (model.to('cuda:N')); there is no CPU "
+                               "fallback in this package")
+        return dv
+
+    # ------------------------------------------------------------------ to be provided
+    def forward_enc(self, enc_input, enc_input_num_pads):
+        raise NotImplementedError
+
+    def _captioner_engine(self) -> "_engine.CaptionerEngine":
+        raise NotImplementedError
+
+    def _enc_lens(self, n: int, S: int, enc_input_num_pads) -> torch.Tensor:
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ decoder API
+    def forward_dec(self, cross_input, enc_input_num_pads, dec_input, dec_input_num_pads,
+                    apply_log_softmax: bool = False):
+        """(N,T) token ids → (N,T,V) logits / log-probs, teacher forced (End_ExpansionNet_v2.py:103-138).
+        Runs the incremental step T times; padded positions reproduce the reference's masked rows."""
+        eng = self._captioner_engine()
+        dv = eng.device
+        cross_input = cross_input.to(dv, torch.float32)
+        dec_input = dec_input.to(dv, torch.int64)
+        N, T = dec_input.shape
+        S = cross_input.shape[1]
+        enc_len = self._enc_lens(N, S, enc_input_num_pads)
+        kv = eng.project_kv(cross_input)
+        st = eng.new_state(N, 1, T + 1, kv, enc_len)
+        st.anc.copy_(torch.arange(N, dtype=torch.int32, device=dv)[:, None].expand(N, T + 1))
+        dec_len = torch.as_tensor([T - int(p) for p in _as_list(dec_input_num_pads, N)], device=dv)
+        V = eng.g.vocab_size
+        out = torch.empty(N, T, V, dtype=torch.float32, device=dv)
+        for t in range(T):
+            st.pos.fill_(t)
+            st.next_tok.copy_(dec_input[:, t])
+            st.row_valid.copy_((dec_len > t).to(torch.int32))
+            eng.step_logits(st)
+            if apply_log_softmax:
+                ops.logsoftmax_topk(st.logits, V, out[:, t], T * V, st.cand_val, st.cand_idx, N, V, 1)
+            else:
+                out[:, t].copy_(st.logits)
+        return out
+
+    def forward(self, enc_x, dec_x=None, enc_x_num_pads=[0], dec_x_num_pads=[0], apply_log_softmax=False,
+                mode="forward", **kwargs):
+        if mode == "forward":
+            x = self.forward_enc(enc_x, enc_x_num_pads)
+            return self.forward_dec(x, enc_x_num_pads, dec_x, dec_x_num_pads, apply_log_softmax)
+        assert ("sos_idx" in kwargs.keys() or "eos_idx" in kwargs.keys()), \
+            "sos and eos must be provided in case of batch sampling or beam search"
+        sos_idx = kwargs.get("sos_idx", -999)
+        eos_idx = kwargs.get("eos_idx", -999)
+        if mode == "beam_search":
+            return self.beam_search(enc_x, enc_x_num_pads, sos_idx=sos_idx, eos_idx=eos_idx,
+                                    beam_size=kwargs.get("beam_size", 5),
+                                    how_many_outputs=kwargs.get("how_many_outputs", 1),
+                                    max_seq_len=kwargs.get("beam_max_seq_len", 20),
+                                    sample_or_max=kwargs.get("sample_or_max", "max"))
+        if mode == "sampling":
+            return self.get_batch_multiple_sampled_prediction(
+                enc_x, enc_x_num_pads, num_outputs=kwargs.get("how_many_outputs", 1), sos_idx=sos_idx,
+                eos_idx=eos_idx, max_seq_len=kwargs.get("sample_max_seq_len", 20))
+        raise ValueError(f"unknown mode {mode!r}")
+
+    def get_batch_multiple_sampled_prediction(self, enc_input, enc_input_num_pads, num_outputs, sos_idx, eos_idx,
+                                              max_seq_len):
+        raise NotImplementedError("mode='sampling' (SCST sampling, SURVEY §8(f) F3) is not part of the "
+                                  "accelerated inference path yet")
+
+    # ------------------------------------------------------------------ search
+    def beam_search(self, enc_input, enc_input_num_pads, sos_idx, eos_idx, beam_size=3, how_many_outputs=1,
+                    max_seq_len=20, sample_or_max="max"):
+        assert (how_many_outputs <= beam_size), "requested output per sequence must be lower than beam width"
+        assert (sample_or_max == "max" or sample_or_max == "sample"), \
+            "argument must be chosen between 'max' and 'sample'"
+        if sample_or_max == "sample":
+            raise NotImplementedError("sample_or_max='sample' (SURVEY §8(f) F3) is not accelerated yet")
+        mem = self.forward_enc(enc_input, enc_input_num_pads)
+        return self._search_from_memory(mem, enc_input_num_pads, sos_idx, eos_idx, beam_size, how_many_outputs,
+                                        max_seq_len)
+
+    def _search_from_memory(self, mem, enc_input_num_pads, sos_idx, eos_idx, beam_size, how_many_outputs,
+                            max_seq_len) -> Tuple[List[List[List[int]]], torch.Tensor]:
+        eng = self._captioner_engine()
+        dv = eng.device
+        B, S, _ = mem.shape
+        k = beam_size
+        steps = max(1, max_seq_len - 1)            # positions 0 .. steps-1 are fed; prefixes reach steps+1
+        T = steps + 1
+        enc_len = self._enc_lens(B, S, enc_input_num_pads)
+        st = eng.new_state(B, k, T, eng.project_kv(mem), enc_len)
+        st.tokens[:, :, 0] = sos_idx
+        st.next_tok.fill_(sos_idx)
+        for t in range(steps):
+            eng.beam_step(st, eos_idx)
+            if t >= 1 and (t + 1) % _DONE_POLL == 0 and t + 1 < steps and int(st.done.item()):
+                break
+        order = torch.empty(B, k, dtype=torch.int32, device=dv)
+        score = torch.empty(B, k, dtype=torch.float32, device=dv)
+        ops.beam_finalize(st.beam_state, order, score, B, k)
+        order_h = order.cpu()
+        n_elem_h = st.n_elem.view(B, k).cpu()
+        tokens_h = st.tokens.cpu()
+        res_tok: List[List[List[int]]] = []
+        lp_rows = []
+        for b in range(B):
+            per = []
+            for j in range(how_many_outputs):
+                i = int(order_h[b, j])
+                n = int(n_elem_h[b, i])
+                per.append(tokens_h[b, i, :n].tolist())
+                lp_rows.append(st.logprobs[b, i, :n])
+            res_tok.append(per)
+        lp = torch.nn.utils.rnn.pad_sequence(lp_rows, batch_first=True).view(B, how_many_outputs, -1)
+        return res_tok, lp
+
+
+def _as_list(pads, n: int) -> List[int]:
+    if isinstance(pads, torch.Tensor):
+        pads = pads.tolist()
+    pads = list(pads)
+    if len(pads) != n:
+        raise RuntimeError(f"expected {n} pad counts, got {len(pads)}")
+    return [int(p) for p in pads]
+
+
+# =================================================================================================
+# refactored API  (models/captioning_model.py:40-110, models/End_ExpansionNet_v2.py:311-354)
+# =================================================================================================
+class Captioner:
+    def __init__(self, beam_search_args, model=None, split_encoder=False, apply_log_softmax=False, encoder=None,
+                 decoder=None):
+        self.rank = None
+        self.split_encoder = split_encoder
+        if self.split_encoder:
+            self.encoder, self.decoder = encoder, decoder
+            if self.encoder is None or self.decoder is None:
+                raise ValueError("Both encoder and decoder must be supplied in Split Encoder mode")
+            raise NotImplementedError("split encoder/decoder modules exist for the reference's FX int8 "
+                                      "quantisation route, which is out of scope (SURVEY §2 row 21)")
+        self.model = model
+        if self.model is None:
+            raise ValueError("An Encoder-Decoder model must be provided")
+        self.beam_search_args = beam_search_args
+        self.apply_log_softmax = apply_log_softmax
+
+    def __call__(self, enc_x, dec_x=None, enc_x_num_pads=[0], dec_x_num_pads=[0], mode="beam_search"):
+        assert ("sos_idx" in self.beam_search_args.keys() or "eos_idx" in self.beam_search_args.keys()), \
+            "sos and eos must be provided in case of batch sampling or beam search"
+        sos_idx = self.beam_search_args["sos_idx"]
+        eos_idx = self.beam_search_args["eos_idx"]
+        a = self.beam_search_args
+        if mode == "beam_search":
+            self.apply_log_softmax = True
+            return self.model.beam_search(enc_x, enc_x_num_pads, sos_idx=sos_idx, eos_idx=eos_idx,
+                                          beam_size=a.get("beam_size", 5),
+                                          how_many_outputs=a.get("how_many_outputs", 1),
+                                          max_seq_len=a.get("beam_max_seq_len", 20),
+                                          sample_or_max=a.get("sample_or_max", "max"))
+        if mode == "sampling":
+            self.apply_log_softmax = True
+            return self.model.get_batch_multiple_sampled_prediction(
+                enc_x, enc_x_num_pads, num_outputs=a.get("how_many_outputs", 1), sos_idx=sos_idx, eos_idx=eos_idx,
+                max_seq_len=a.get("sample_max_seq_len", 20))
+        raise ValueError(f"unknown mode {mode!r}")
+
+    def forward_enc(self, enc_input, enc_input_num_pads):
+        return self.model.forward_enc(enc_input, enc_input_num_pads)
+
+    def forward_dec(self, cross_input, enc_input_num_pads, dec_input, dec_input_num_pads):
+        return self.model.forward_dec(cross_input, enc_input_num_pads, dec_input, dec_input_num_pads,
+                                      self.apply_log_softmax)
+
+    def beam_search(self, *a, **k):
+        return self.model.beam_search(*a, **k)

@@ -1,0 +1,292 @@
+"""Host-side sequencing of the HIP kernels: Swin backbone, expansion encoder, incremental decoder.
+
+Everything here is plumbing: weights are packed once per (state dict, device, precision) into the
+layouts the kernels want, activations live in torch-owned device buffers, and every arithmetic
+step is a call into libodic_hip.so on the current stream (so a whole forward can be captured into
+a hipGraph by `torch.cuda.graph`).  There is no CPU path.
+
+Data layout in HBM
+  * residual stream            fp32 [B·L, C]  (both precisions; 24 blocks deep, kept exact)
+  * LN outputs / qkv / attention out / MLP hidden   fp32 or bf16 [B·L, *] token-major, never
+    window-permuted: the (shifted) window gather/scatter happens inside the attention kernel
+  * encoder / decoder          fp32; per-layer residual streams are column slices of one
+    [rows, N_layers·d] buffer so the reference's torch.cat (End_ExpansionNet_v2.py:97,133) is free
+  * decoder caches             [T, N, ...] indexed by (position, slot) + an ancestor table
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _hip, ops
+from .weights import Geometry
+
+SD = Dict[str, torch.Tensor]
+_CDT = {"fp32": torch.float32, "bf16": torch.bfloat16}
+
+
+def _dev(t: torch.Tensor, device, dtype=None) -> torch.Tensor:
+    t = t.detach()
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.to(device).contiguous()
+
+
+# =================================================================================================
+# Swin backbone  
+# =================================================================================================
+class SwinEngine:
+    def __init__(self, sd: SD, g: Geometry, device, precision: str = "fp32"):
+        if precision not in _CDT:
+            raise ValueError(f"precision must be one of {list(_CDT)}")
+        self.g, self.device, self.precision = g, device, precision
+        self.cdt = _CDT[precision]
+        P = "swin_transf"
+        f32 = lambda k: _dev(sd[k], device, torch.float32)          # noqa: E731
+        cw = lambda k: _dev(sd[k], device, torch.float32).to(self.cdt).contiguous()   # noqa: E731
+        self.pe_w = _dev(sd[f"{P}.patch_embed.proj.weight"].reshape(g.swin_embed_dim, -1), device, torch.float32)
+        self.pe_b = f32(f"{P}.patch_embed.proj.bias")
+        self.pe_g, self.pe_beta = f32(f"{P}.patch_embed.norm.weight"), f32(f"{P}.patch_embed.norm.bias")
+        self.stages = []
+        for s, depth in enumerate(g.swin_depths):
+            blocks = []
+            for b in range(depth):
+                p = f"{P}.layers.{s}.blocks.{b}"
+                blocks.append(dict(
+                    n1w=f32(p + ".norm1.weight"), n1b=f32(p + ".norm1.bias"),
+                    qkv_w=cw(p + ".attn.qkv.weight"), qkv_b=f32(p + ".attn.qkv.bias"),
+                    table=f32(p + ".attn.relative_position_bias_table"),
+                    proj_w=cw(p + ".attn.proj.weight"), proj_b=f32(p + ".attn.proj.bias"),
+                    n2w=f32(p + ".norm2.weight"), n2b=f32(p + ".norm2.bias"),
+                    fc1_w=cw(p + ".mlp.fc1.weight"), fc1_b=f32(p + ".mlp.fc1.bias"),
+                    fc2_w=cw(p + ".mlp.fc2.weight"), fc2_b=f32(p + ".mlp.fc2.bias"),
+                    shift=g.stage_shift(s, b)))
+            down = None
+            if s < len(g.swin_depths) - 1:
+                p = f"{P}.layers.{s}.downsample"
+                down = dict(nw=f32(p + ".norm.weight"), nb=f32(p + ".norm.bias"), red_w=cw(p + ".reduction.weight"))
+            self.stages.append((blocks, down))
+        self.fn_w, self.fn_b = f32(f"{P}.norm.weight"), f32(f"{P}.norm.bias")
+
+    def forward(self, img: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        """img fp32 [B,3,H,W] on the engine's device → features fp32 [B, res_last², C_last]."""
+        g, cdt = self.g, self.cdt
+        if img.dtype != torch.float32 or not img.is_cuda:
+            raise RuntimeError("SwinEngine.forward wants an fp32 CUDA image batch")
+        img = img.contiguous()
+        B = img.shape[0]
+        x = ops.patch_embed(img, self.pe_w, self.pe_b, self.pe_g, self.pe_beta, g.swin_patch_size)
+        if taps is not None:
+            taps["patch_embed"] = x.clone()
+        for s, (blocks, down) in enumerate(self.stages):
+            res, C_, heads, ws = g.stage_res(s), g.stage_dim(s), g.swin_num_heads[s], g.stage_window(s)
+            x = x.view(B * res * res, C_)
+            for bi, w in enumerate(blocks):
+                xn = ops.layernorm(x, w["n1w"], w["n1b"], out_dtype=cdt)
+                qkv = ops.gemm(xn, w["qkv_w"], w["qkv_b"])
+                att = ops.window_attention(qkv, w["table"], B, res, C_, heads, ws, w["shift"])
+                ops.gemm(att, w["proj_w"], w["proj_b"], residual=x, out=x)
+                xn = ops.layernorm(x, w["n2w"], w["n2b"], out_dtype=cdt)
+                h = ops.gemm(xn, w["fc1_w"], w["fc1_b"], act=ops.ACT_GELU)
+                ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x)
+                if taps is not None:
+                    taps[f"s{s}b{bi}"] = x.view(B, res * res, C_).clone()
+            if down is not None:
+                xm = ops.patch_merge_layernorm(x, down["nw"], down["nb"], B, res, C_, out_dtype=cdt)
+                x = ops.gemm(xm.view(-1, 4 * C_), down["red_w"], out_dtype=torch.float32)
+                if taps is not None:
+                    taps[f"merge{s}"] = x.view(B, (res // 2) ** 2, 2 * C_).clone()
+        res = g.stage_res(len(g.swin_depths) - 1)
+        out = ops.layernorm(x, self.fn_w, self.fn_b, out_dtype=torch.float32)
+        return out.view(B, res * res, -1)
+
+
+# =================================================================================================
+# Expansion encoder + decoder, fp32
+# =================================================================================================
+class DecodeState:
+    """Device-resident state of one search / teacher-forced run (see include/odic_hip.h)."""
+
+    def __init__(self, eng: "CaptionerEngine", n_img: int, beams: int, T: int, kv: torch.Tensor,
+                 enc_len: torch.Tensor, S: int):
+        g, dv = eng.g, eng.device
+        N = n_img * beams
+        d, E, L = g.d_model, g.num_exp_dec, g.N_dec
+        self.n_img, self.beams, self.N, self.T, self.S = n_img, beams, N, T, S
+        self.kv, self.enc_len = kv, enc_len
+        f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dv)      # noqa: E731
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dv)      # noqa: E731
+        self.ycat = f(N, L * d)
+        self.caches = [dict(cond=f(T, N, d), key=f(T, N, d), va=f(T, N, d), vb=f(T, N, d),
+                            afull=f(T, N, E, d), bfull=f(T, N, E, d), qk=f(T, N, E)) for _ in range(L)]
+        self.anc = i32(N, T)
+        self.row_valid = torch.ones(N, dtype=torch.int32, device=dv)
+        self.next_tok = torch.zeros(N, dtype=torch.int64, device=dv)
+        self.pos, self.done = i32(1), i32(1)
+        self.tokens = torch.zeros(n_img, beams, T, dtype=torch.int64, device=dv)
+        self.logprobs = f(n_img, beams, T)
+        self.cumul, self.n_elem, self.has_eos = f(N), i32(N), i32(N)
+        self.cand_val, self.cand_idx = f(N, beams), i32(N, beams)
+        self.logits = f(N, g.vocab_size)
+        self.beam_state = _hip.BeamState(*(t.data_ptr() for t in (
+            self.tokens, self.logprobs, self.anc, self.cumul, self.n_elem, self.has_eos, self.row_valid,
+            self.next_tok, self.pos, self.done)))
+
+
+class CaptionerEngine:
+    def __init__(self, sd: SD, g: Geometry, device):
+        self.g, self.device = g, device
+        d = g.d_model
+        f32 = lambda k: _dev(sd[k], device, torch.float32)          # noqa: E731
+        cat = lambda ks: torch.cat([f32(k) for k in ks], 0).contiguous()   # noqa: E731
+        self.in_w, self.in_b = f32("input_linear.weight"), f32("input_linear.bias")
+        self.enc = []
+        for i in range(g.N_enc):
+            p = f"encoders.{i}"
+            s = p + ".stc_exp"
+            self.enc.append(dict(
+                n1w=f32(p + ".norm_1.weight"), n1b=f32(p + ".norm_1.bias"),
+                n2w=f32(p + ".norm_2.weight"), n2b=f32(p + ".norm_2.bias"),
+                q=f32(s + ".query_exp_vectors.weight"),
+                bvT=f32(s + ".bias_exp_vectors.weight").t().contiguous(),              # [d, nq]
+                ks_w=cat([s + ".key_embed.weight", s + ".selector_embed.weight"]),     # [2d, d]
+                ks_b=cat([s + ".key_embed.bias", s + ".selector_embed.bias"]),
+                ab_w=cat([s + ".class_a_embed.weight", s + ".class_b_embed.weight"]),  # [2d, d]
+                ab_b=cat([s + ".class_a_embed.bias", s + ".class_b_embed.bias"]),
+                f1w=f32(p + ".ff.linear_1.weight"), f1b=f32(p + ".ff.linear_1.bias"),
+                f2w=f32(p + ".ff.linear_2.weight"), f2b=f32(p + ".ff.linear_2.bias")))
+        self.er_w, self.er_b = f32("enc_reduce_group.weight"), f32("enc_reduce_group.bias")
+        self.ern_w, self.ern_b = f32("enc_reduce_norm.weight"), f32("enc_reduce_norm.bias")
+        self.group_meta = ops.stcexp_group_meta(g.num_exp_enc_list, device)
+        self.dec = []
+        kvw, kvb = [], []
+        for i in range(g.N_dec):
+            p = f"decoders.{i}"
+            s = p + ".dyn_exp"
+            names = ["cond_embed", "key_linear", "class_a_embed", "class_b_embed", "selector_embed"]
+            self.dec.append(dict(
+                n1w=f32(p + ".norm_1.weight"), n1b=f32(p + ".norm_1.bias"),
+                n2w=f32(p + ".norm_2.weight"), n2b=f32(p + ".norm_2.bias"),
+                n3w=f32(p + ".norm_3.weight"), n3b=f32(p + ".norm_3.bias"),
+                dyn_w=cat([f"{s}.{n}.weight" for n in names]), dyn_b=cat([f"{s}.{n}.bias" for n in names]),
+                qexp=f32(s + ".query_exp_vectors.weight"), bexp=f32(s + ".bias_exp_vectors.weight"),
+                wq=f32(p + ".mha.Wq.weight"), bq=f32(p + ".mha.Wq.bias"),
+                wo=f32(p + ".mha.out_linear.weight"), bo=f32(p + ".mha.out_linear.bias"),
+                f1w=f32(p + ".ff.linear_1.weight"), f1b=f32(p + ".ff.linear_1.bias"),
+                f2w=f32(p + ".ff.linear_2.weight"), f2b=f32(p + ".ff.linear_2.bias")))
+            kvw += [p + ".mha.Wk.weight", p + ".mha.Wv.weight"]
+            kvb += [p + ".mha.Wk.bias", p + ".mha.Wv.bias"]
+        self.kv_w, self.kv_b = cat(kvw), cat(kvb)                   # [2·N_dec·d, d]
+        self.dr_w, self.dr_b = f32("dec_reduce_group.weight"), f32("dec_reduce_group.bias")
+        self.drn_w, self.drn_b = f32("dec_reduce_norm.weight"), f32("dec_reduce_norm.bias")
+        self.voc_w, self.voc_b = f32("vocab_linear.weight"), f32("vocab_linear.bias")
+        self.embed, self.pos_table = f32("out_embedder.embed.weight"), f32("pos_encoder.weight")
+
+    # ------------------------------------------------------------------------------------------
+    def encode(self, feats: torch.Tensor, enc_len: torch.Tensor) -> torch.Tensor:
+        """feats fp32 [B,S,F] → encoder output fp32 [B,S,d]  (forward_enc after the backbone:
+        End_ExpansionNet_v2.py:82-101 / ExpansionNet_v2.py:52-70).  enc_len int32 [B] on device."""
+        g, dv = self.g, self.device
+        B, S, F = feats.shape
+        d, L, nq, M = g.d_model, g.N_enc, sum(g.num_exp_enc_list), B * S
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dv)      # noqa: E731
+        x0 = ops.gemm(feats.reshape(M, F).contiguous(), self.in_w, self.in_b)            # [M,d]
+        xcat = f(M, L * d)
+        z, pf, nf = f(B, nq, S), f(B, nq, S), f(B, nq, S)
+        pb, nb = f(B, S, nq), f(B, S, nq)
+        colsum = f(B * len(g.num_exp_enc_list) * 2 * S)
+        AT, BT = f(B, d, nq), f(B, d, nq)
+        A2, B2 = f(B, S, d), f(B, S, d)
+        vabT = f(B, 2 * d, S)
+        ld = L * d
+        for i, w in enumerate(self.enc):
+            xin, ldin = (x0, d) if i == 0 else (xcat[:, (i - 1) * d:], ld)
+            xo = xcat[:, i * d:]
+            x2 = ops.layernorm(xin, w["n1w"], w["n1b"], M=M, C_=d, ldx=ldin)
+            lin = ops.gemm(x2, w["ks_w"], w["ks_b"])                                         # key | sel
+            # (class_a | class_b) projections, produced transposed: [B, 2d, S] = W·x2ᵀ + b(row)
+            ops.gemm(w["ab_w"], x2, w["ab_b"], out=vabT, bias_axis=1, M=2 * d, N=S, K=d, lda=d, ldw=d, ldc=S,
+                     batch=B, strideA=0, strideW=S * d, strideC=2 * d * S)
+            # z = Q·Kᵀ/sqrt(d)
+            ops.gemm(w["q"], lin, out=z, alpha=1.0 / math.sqrt(d), M=nq, N=S, K=d, lda=d, ldw=2 * d, ldc=S,
+                     batch=B, strideA=0, strideW=S * 2 * d, strideC=nq * S)
+            ops.stcexp_normalize(z, enc_len, self.group_meta, len(g.num_exp_enc_list), pf, nf, pb, nb, colsum)
+            # class_aᵀ [d,nq] = Vaᵀ·pos_fwᵀ + Bvᵀ    (layers.py:63-64, transposed)
+            ops.gemm(vabT, pf, residual=w["bvT"], out=AT, M=d, N=nq, K=S, lda=S, ldw=S, ldr=nq, ldc=nq, batch=B,
+                     strideA=2 * d * S, strideW=nq * S, strideR=0, strideC=d * nq)
+            ops.gemm(vabT[:, d:], nf, residual=w["bvT"], out=BT, M=d, N=nq, K=S, lda=S, ldw=S, ldr=nq, ldc=nq,
+                     batch=B, strideA=2 * d * S, strideW=nq * S, strideR=0, strideC=d * nq)
+            # backward: [S,nq]·[nq,d]
+            ops.gemm(pb, AT, out=A2, M=S, N=d, K=nq, lda=nq, ldw=nq, ldc=d, batch=B, strideA=S * nq,
+                     strideW=d * nq, strideC=S * d)
+            ops.gemm(nb, BT, out=B2, M=S, N=d, K=nq, lda=nq, ldw=nq, ldc=d, batch=B, strideA=S * nq,
+                     strideW=d * nq, strideC=S * d)
+            ops.selector_mix(xin, ldin, lin[:, d:], 2 * d, A2, d, B2, d, xo, ld, M, d)
+            x2 = ops.layernorm(xo, w["n2w"], w["n2b"], M=M, C_=d, ldx=ld)
+            h = ops.gemm(x2, w["f1w"], w["f1b"], act=ops.ACT_RELU)
+            ops.gemm(h, w["f2w"], w["f2b"], residual=xo, out=xo, M=M, N=d, K=g.ff, lda=g.ff, ldw=g.ff, ldr=ld,
+                     ldc=ld)
+        pre = ops.gemm(xcat, self.er_w, self.er_b, residual=xcat[:, (L - 1) * d:], M=M, N=d, K=L * d, lda=ld,
+                       ldw=ld, ldr=ld, ldc=d, out=f(M, d))
+        mem = ops.layernorm(pre, self.ern_w, self.ern_b)
+        return mem.view(B, S, d)
+
+    def project_kv(self, mem: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Cross-attention K/V of every decoder layer, once per image (the reference recomputes them
+        every step for every beam, layers.py:274-276): [B,S,d] → [B,S,2·N_dec·d]."""
+        B, S, d = mem.shape
+        n = self.kv_w.shape[0]
+        if out is None:
+            out = torch.empty(B, S, n, dtype=torch.float32, device=self.device)
+        ops.gemm(mem.reshape(B * S, d).contiguous(), self.kv_w, self.kv_b, out=out, M=B * S, N=n, K=d, lda=d, ldw=d,
+                 ldc=n)
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def new_state(self, n_img: int, beams: int, T: int, kv: torch.Tensor, enc_len: torch.Tensor) -> DecodeState:
+        if T > 128:
+            raise RuntimeError("decode length > 128 positions is not supported by odic_dynexp_step")
+        if T - 1 > self.pos_table.shape[0]:
+            raise RuntimeError(f"{T - 1} decode positions exceed the pos_encoder table ({self.pos_table.shape[0]})")
+        return DecodeState(self, n_img, beams, T, kv, enc_len, kv.shape[1])
+
+    def step_logits(self, st: DecodeState) -> None:
+        """Process position *st.pos for every sequence: next_tok → st.logits [N,V]."""
+        g = self.g
+        d, L, N = g.d_model, g.N_dec, st.N
+        ld = L * d
+        ops.dec_embed(st.next_tok, self.embed, self.pos_table, st.pos, st.ycat, ld, N, d, math.sqrt(d))
+        for i, w in enumerate(self.dec):
+            c = st.caches[i]
+            xin = st.ycat if i == 0 else st.ycat[:, (i - 1) * d:]
+            xo = st.ycat[:, i * d:]
+            x2 = ops.layernorm(xin, w["n1w"], w["n1b"], M=N, C_=d, ldx=ld)
+            lin = ops.gemm(x2, w["dyn_w"], w["dyn_b"])                                       # [N,5d]
+            ops.dynexp_step(lin, 5 * d, w["qexp"], w["bexp"], c["cond"], c["key"], c["va"], c["vb"], c["afull"],
+                            c["bfull"], c["qk"], st.anc, st.row_valid, st.pos, xin, ld, xo, ld, N, st.T, d,
+                            g.num_exp_dec)
+            x2 = ops.layernorm(xo, w["n2w"], w["n2b"], M=N, C_=d, ldx=ld)
+            q = ops.gemm(x2, w["wq"], w["bq"])
+            att = torch.empty(N, d, dtype=torch.float32, device=self.device)
+            ops.cross_attn_step(q, d, st.kv, st.kv.shape[2], 2 * i * d, (2 * i + 1) * d, st.enc_len,
+                                st.row_valid, att, d, N, st.n_img, st.S, d, g.num_heads)
+            ops.gemm(att, w["wo"], w["bo"], residual=xo, out=xo, M=N, N=d, K=d, lda=d, ldw=d, ldr=ld, ldc=ld)
+            x2 = ops.layernorm(xo, w["n3w"], w["n3b"], M=N, C_=d, ldx=ld)
+            h = ops.gemm(x2, w["f1w"], w["f1b"], act=ops.ACT_RELU)
+            ops.gemm(h, w["f2w"], w["f2b"], residual=xo, out=xo, M=N, N=d, K=g.ff, lda=g.ff, ldw=g.ff, ldr=ld,
+                     ldc=ld)
+        pre = torch.empty(N, d, dtype=torch.float32, device=self.device)
+        ops.gemm(st.ycat, self.dr_w, self.dr_b, residual=st.ycat[:, (L - 1) * d:], out=pre, M=N, N=d, K=ld, lda=ld,
+                 ldw=ld, ldr=ld, ldc=d)
+        zf = ops.layernorm(pre, self.drn_w, self.drn_b)
+        ops.gemm(zf, self.voc_w, self.voc_b, out=st.logits)
+
+    def beam_step(self, st: DecodeState, eos_idx: int) -> None:
+        """One full search step: decoder → log-softmax/top-k → on-device beam bookkeeping."""
+        self.step_logits(st)
+        V = self.g.vocab_size
+        ops.logsoftmax_topk(st.logits, V, None, 0, st.cand_val, st.cand_idx, st.N, V, st.beams)
+        ops.beam_step(st.cand_val, st.cand_idx, st.beam_state, st.n_img, st.beams, st.T, eos_idx)

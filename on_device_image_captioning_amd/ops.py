@@ -21,6 +21,47 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ----------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py's roofline pass): HIP events recorded on the launch stream
+# around every C-ABI call, tagged with the kernel family and its algorithmic FLOPs / bytes.
+# ----------------------------------------------------------------------------------------------
+_PROFILE: Optional[list] = None
+
+
+class profile:
+    """`with ops.profile() as recs:` → recs = [(family, flops, bytes, start_evt, end_evt, detail), ...]"""
+
+    def __enter__(self):
+        global _PROFILE
+        _PROFILE = []
+        return _PROFILE
+
+    def __exit__(self, *exc):
+        global _PROFILE
+        _PROFILE = None
+        return False
+
+
+class _timed:
+    __slots__ = ("family", "flops", "bytes", "start", "detail")
+
+    def __init__(self, family: str, flops: float, nbytes: float, detail: str = ""):
+        self.family, self.flops, self.bytes, self.start, self.detail = family, flops, nbytes, None, detail
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.start is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            _PROFILE.append((self.family, self.flops, self.bytes, self.start, end, self.detail))
+        return False
+
+
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -77,7 +118,13 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
     a = _hip.GemmArgs(_p(A), _p(W), _p(bias), _p(residual), _p(out), M, N, K, lda, ldw, ldr or 0, ldc, batch,
                       strideA, strideW, strideBias, strideR, strideC, alpha, act, bias_axis,
                       dtype_code(A.dtype), dtype_code(out.dtype))
-    _hip.check(_hip.load().odic_gemm(C.byref(a), _stream()), "odic_gemm")
+    isz, osz = A.element_size(), out.element_size()
+    nbytes = batch * ((M * K if strideA or batch == 1 else M * K / batch) * isz +
+                      (N * K if strideW or batch == 1 else N * K / batch) * isz + M * N * osz +
+                      (M * N * 4 if residual is not None else 0))
+    with _timed("gemm_bf16" if A.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * batch, nbytes,
+                f"{M}x{N}x{K}" + (f"x{batch}" if batch > 1 else "")):
+        _hip.check(_hip.load().odic_gemm(C.byref(a), _stream()), "odic_gemm")
     return out
 
 
@@ -93,8 +140,9 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, eps: 
             raise RuntimeError("layernorm: implicit-shape input must be contiguous")
     if out is None:
         out = torch.empty((M, C_) if x.dim() < 2 or ldx != C_ else x.shape, dtype=out_dtype, device=x.device)
-    _hip.check(_hip.load().odic_layernorm(_p(x), ldx, _p(gamma), _p(beta), _p(out), M, C_, eps,
-                                          dtype_code(out.dtype), _stream()), "odic_layernorm")
+    with _timed("layernorm", 8.0 * M * C_, M * C_ * (4 + out.element_size())):
+        _hip.check(_hip.load().odic_layernorm(_p(x), ldx, _p(gamma), _p(beta), _p(out), M, C_, eps,
+                                              dtype_code(out.dtype), _stream()), "odic_layernorm")
     return out
 
 
@@ -102,9 +150,10 @@ def patch_merge_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tens
                           *, eps: float = 1e-5, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
     _need_cuda(x, gamma, beta)
     out = torch.empty((B, (res // 2) ** 2, 4 * Cin), dtype=out_dtype, device=x.device)
-    _hip.check(_hip.load().odic_patch_merge_layernorm(_p(x), _p(gamma), _p(beta), _p(out), B, res, Cin, eps,
-                                                      dtype_code(out_dtype), _stream()),
-               "odic_patch_merge_layernorm")
+    with _timed("patch_merge_layernorm", 8.0 * out.numel(), out.numel() * (4 + out.element_size())):
+        _hip.check(_hip.load().odic_patch_merge_layernorm(_p(x), _p(gamma), _p(beta), _p(out), B, res, Cin, eps,
+                                                          dtype_code(out_dtype), _stream()),
+                   "odic_patch_merge_layernorm")
     return out
 
 
@@ -116,8 +165,9 @@ def patch_embed(img: torch.Tensor, w: torch.Tensor, b: torch.Tensor, gamma: torc
     if not img.is_contiguous() or img.dtype != torch.float32:
         raise RuntimeError("patch_embed: image batch must be contiguous fp32 [B,C,H,W]")
     out = torch.empty((B, (H // patch) * (Wd // patch), Cout), dtype=torch.float32, device=img.device)
-    _hip.check(_hip.load().odic_patch_embed(_p(img), _p(w), _p(b), _p(gamma), _p(beta), _p(out), B, Cin, H, Wd,
-                                            patch, Cout, eps, _stream()), "odic_patch_embed")
+    with _timed("patch_embed", 2.0 * out.numel() * Cin * patch * patch, (img.numel() + out.numel()) * 4):
+        _hip.check(_hip.load().odic_patch_embed(_p(img), _p(w), _p(b), _p(gamma), _p(beta), _p(out), B, Cin, H, Wd,
+                                                patch, Cout, eps, _stream()), "odic_patch_embed")
     return out
 
 
@@ -129,9 +179,14 @@ def window_attention(qkv: torch.Tensor, bias_table: torch.Tensor, B: int, res: i
         scale = (C_ // heads) ** -0.5
     if out is None:
         out = torch.empty((B * res * res, C_), dtype=qkv.dtype, device=qkv.device)
-    _hip.check(_hip.load().odic_window_attention(_p(qkv), _p(bias_table), _p(out), B, res, C_, heads, ws, shift,
-                                                 scale, dtype_code(qkv.dtype), _stream()),
-               "odic_window_attention")
+    # algorithmic work per (window, head): QKᵀ + PV = 4·N²·hd FLOP; q,k,v in + o out = 4·N·hd elements
+    inst = B * (res // ws) ** 2 * heads
+    n = ws * ws
+    with _timed("window_attention_bf16" if qkv.dtype == torch.bfloat16 else "window_attention_f32",
+                inst * 4.0 * n * n * 32, inst * 4.0 * n * 32 * qkv.element_size(), f"res{res}h{heads}"):
+        _hip.check(_hip.load().odic_window_attention(_p(qkv), _p(bias_table), _p(out), B, res, C_, heads, ws, shift,
+                                                     scale, dtype_code(qkv.dtype), _stream()),
+                   "odic_window_attention")
     return out
 
 
@@ -150,51 +205,59 @@ def stcexp_normalize(z: torch.Tensor, enc_len: torch.Tensor, group_meta: torch.T
                      colsum_ws: torch.Tensor, *, eps: float = 1e-9) -> None:
     _need_cuda(z, enc_len, group_meta, pos_fw, neg_fw, pos_bw, neg_bw, colsum_ws)
     B, nq, S = z.shape
-    _hip.check(_hip.load().odic_stcexp_normalize(_p(z), _p(enc_len), _p(group_meta), ngroups, _p(pos_fw),
-                                                 _p(neg_fw), _p(pos_bw), _p(neg_bw), _p(colsum_ws), B, nq, S, eps,
-                                                 _stream()), "odic_stcexp_normalize")
+    with _timed("stcexp_normalize", 0.0, 0.0):
+        _hip.check(_hip.load().odic_stcexp_normalize(_p(z), _p(enc_len), _p(group_meta), ngroups, _p(pos_fw),
+                                                     _p(neg_fw), _p(pos_bw), _p(neg_bw), _p(colsum_ws), B, nq, S, eps,
+                                                     _stream()), "odic_stcexp_normalize")
 
 
 def selector_mix(x, ldx, sel_pre, lds, a, lda, b, ldb, out, ldo, M, d) -> None:
     _need_cuda(x, sel_pre, a, b, out)
-    _hip.check(_hip.load().odic_selector_mix(_p(x), ldx, _p(sel_pre), lds, _p(a), lda, _p(b), ldb, _p(out), ldo,
-                                             M, d, _stream()), "odic_selector_mix")
+    with _timed("selector_mix", 0.0, 0.0):
+        _hip.check(_hip.load().odic_selector_mix(_p(x), ldx, _p(sel_pre), lds, _p(a), lda, _p(b), ldb, _p(out), ldo,
+                                                 M, d, _stream()), "odic_selector_mix")
 
 
 # ----------------------------------------------------------------------------------------------
 def dec_embed(tokens, embed, pos_table, pos, y, ldy, N, d, scale) -> None:
     _need_cuda(tokens, embed, pos_table, pos, y)
-    _hip.check(_hip.load().odic_dec_embed(_p(tokens), _p(embed), _p(pos_table), _p(pos), _p(y), ldy, N, d, scale,
-                                          _stream()), "odic_dec_embed")
+    with _timed("dec_embed", 0.0, 0.0):
+        _hip.check(_hip.load().odic_dec_embed(_p(tokens), _p(embed), _p(pos_table), _p(pos), _p(y), ldy, N, d, scale,
+                                              _stream()), "odic_dec_embed")
 
 
 def dynexp_step(lin, ldlin, qexp, bexp, cond_c, key_c, va_c, vb_c, afull_c, bfull_c, qk_c, anc, row_valid, pos,
                 y_in, ldy_in, y, ldy, N, T, d, E, eps=1e-9) -> None:
     _need_cuda(lin, qexp, bexp, cond_c, key_c, va_c, vb_c, afull_c, bfull_c, qk_c, anc, row_valid, pos, y_in, y)
-    _hip.check(_hip.load().odic_dynexp_step(_p(lin), ldlin, _p(qexp), _p(bexp), _p(cond_c), _p(key_c), _p(va_c),
-                                            _p(vb_c), _p(afull_c), _p(bfull_c), _p(qk_c), _p(anc), _p(row_valid),
-                                            _p(pos), _p(y_in), ldy_in, _p(y), ldy, N, T, d, E, eps, _stream()),
-               "odic_dynexp_step")
+    with _timed("dynexp_step", 0.0, 0.0):
+        _hip.check(_hip.load().odic_dynexp_step(_p(lin), ldlin, _p(qexp), _p(bexp), _p(cond_c), _p(key_c), _p(va_c),
+                                                _p(vb_c), _p(afull_c), _p(bfull_c), _p(qk_c), _p(anc), _p(row_valid),
+                                                _p(pos), _p(y_in), ldy_in, _p(y), ldy, N, T, d, E, eps, _stream()),
+                   "odic_dynexp_step")
 
 
 def cross_attn_step(q, ldq, kv, ldkv, koff, voff, enc_len, row_valid, out, ldo, N, n_img, S, d, heads) -> None:
     _need_cuda(q, kv, enc_len, row_valid, out)
-    _hip.check(_hip.load().odic_cross_attn_step(_p(q), ldq, _p(kv), ldkv, koff, voff, _p(enc_len), _p(row_valid),
-                                                _p(out), ldo, N, n_img, S, d, heads, _stream()),
-               "odic_cross_attn_step")
+    with _timed("cross_attn_step", 0.0, 0.0):
+        _hip.check(_hip.load().odic_cross_attn_step(_p(q), ldq, _p(kv), ldkv, koff, voff, _p(enc_len), _p(row_valid),
+                                                    _p(out), ldo, N, n_img, S, d, heads, _stream()),
+                   "odic_cross_attn_step")
 
 
 def logsoftmax_topk(logits, ldl, logp_out, ldp, top_val, top_idx, N, V, k) -> None:
     _need_cuda(logits, logp_out, top_val, top_idx)
-    _hip.check(_hip.load().odic_logsoftmax_topk(_p(logits), ldl, _p(logp_out), ldp, _p(top_val), _p(top_idx), N, V,
-                                                k, _stream()), "odic_logsoftmax_topk")
+    with _timed("logsoftmax_topk", 0.0, 0.0):
+        _hip.check(_hip.load().odic_logsoftmax_topk(_p(logits), ldl, _p(logp_out), ldp, _p(top_val), _p(top_idx), N, V,
+                                                    k, _stream()), "odic_logsoftmax_topk")
 
 
 def beam_step(cand_val, cand_idx, state: "_hip.BeamState", n_img, beams, T, eos_idx) -> None:
-    _hip.check(_hip.load().odic_beam_step(_p(cand_val), _p(cand_idx), C.byref(state), n_img, beams, T, eos_idx,
-                                          _stream()), "odic_beam_step")
+    with _timed("beam_step", 0.0, 0.0):
+        _hip.check(_hip.load().odic_beam_step(_p(cand_val), _p(cand_idx), C.byref(state), n_img, beams, T, eos_idx,
+                                              _stream()), "odic_beam_step")
 
 
 def beam_finalize(state: "_hip.BeamState", order, score, n_img, beams) -> None:
-    _hip.check(_hip.load().odic_beam_finalize(C.byref(state), _p(order), _p(score), n_img, beams, _stream()),
-               "odic_beam_finalize")
+    with _timed("beam_finalize", 0.0, 0.0):
+        _hip.check(_hip.load().odic_beam_finalize(C.byref(state), _p(order), _p(score), n_img, beams, _stream()),
+                   "odic_beam_finalize")

@@ -91,6 +91,14 @@ TINY = Geometry(swin_embed_dim=96, swin_depths=(2, 2, 2, 2), swin_num_heads=(3, 
                 N_enc=2, N_dec=2)
 
 
+#: TINY with channel counts that are multiples of 64 (the bf16 MFMA GEMM needs K % 64 == 0, which every
+#: Swin-L stage satisfies: 192·2^s).  No golden fixture: compared against the live oracle.
+TINY64 = Geometry(swin_embed_dim=128, swin_depths=(2, 2, 2, 2), swin_num_heads=(4, 8, 16, 32),
+                  final_swin_dim=1024, d_model=128, ff=256, num_heads=4,
+                  num_exp_enc_list=(8, 16, 24), num_exp_dec=4, vocab_size=500, max_seq_len=24,
+                  N_enc=2, N_dec=2)
+
+
 # ----------------------------------------------------------------------------------------------
 # constant buffers
 # ----------------------------------------------------------------------------------------------
