@@ -72,6 +72,10 @@ typedef struct odic_gemm_args {
 } odic_gemm_args;
 int odic_gemm(const odic_gemm_args* args, void* stream);
 
+/* Tuning / test hook: force the bf16 tile configuration (0: 128x64, 1: 128x128, 2: 256x256,
+ * -1: automatic choice).  Process-global; not for production use. */
+void odic_gemm_bf16_force_config(int cfg);
+
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps inside sqrt, biased variance — torch.nn.LayerNorm).
  *   x fp32 [M,C] (ldx) → out `out_dtype` [M,C] contiguous.   C % 4 == 0, C <= 8192.
@@ -158,13 +162,14 @@ int odic_dec_embed(const int64_t* tokens, const float* embed, const float* pos_t
  *   row_valid int32 [N]: 0 → padded row (finished beam): the block contributes 0 (masked rows of
  *        utils/masking.py:37-47), caches are still written.
  *   y_in fp32 [N,d] (ldy_in) → y fp32 [N,d] (ldy):  y = y_in + sel·A' + (1-sel)·B'  (may alias).
- *   T <= 128, E <= 32.
+ *   scratch fp32 [N, 4·T·E + T]: normalised weight tables handed from the score kernel to the
+ *        accumulation kernel.   T <= 128, E in {4, 8, 16, 32}.
  */
 int odic_dynexp_step(const float* lin, int64_t ldlin, const float* qexp, const float* bexp,
                      float* cond_c, float* key_c, float* va_c, float* vb_c, float* afull_c,
                      float* bfull_c, float* qk_c, const int32_t* anc, const int32_t* row_valid,
                      const int32_t* pos, const float* y_in, int64_t ldy_in, float* y, int64_t ldy,
-                     int32_t N, int32_t T, int32_t d, int32_t E, float eps, void* stream);
+                     float* scratch, int32_t N, int32_t T, int32_t d, int32_t E, float eps, void* stream);
 
 /* Cross attention of one query row per sequence against per-IMAGE cached K/V (layers.py:266-295;
  * the reference re-projects K/V of the 144 encoder tokens every step for every beam copy).
@@ -172,7 +177,7 @@ int odic_dynexp_step(const float* lin, int64_t ldlin, const float* qexp, const f
  *   kv fp32 [n_img, S, ldkv]: projected keys at column koff, values at column voff;
  *   enc_len int32 [n_img]; beams = N / n_img; row_valid as above (0 → all scores masked to -1e4,
  *   i.e. a uniform average over all S positions, exactly what masked_fill + softmax gives).
- *   out fp32 [N, d] (ldo) = softmax(q·kᵀ/sqrt(d/heads))·v, heads concatenated.  d % 64 == 0. */
+ *   out fp32 [N, d] (ldo) = softmax(q·kᵀ/sqrt(d/heads))·v, heads concatenated.  d/heads in {16,32,64}. */
 int odic_cross_attn_step(const float* q, int64_t ldq, const float* kv, int64_t ldkv, int32_t koff,
                          int32_t voff, const int32_t* enc_len, const int32_t* row_valid, float* out,
                          int64_t ldo, int32_t N, int32_t n_img, int32_t S, int32_t d, int32_t heads,

@@ -68,10 +68,16 @@ struct DynParams {
   const float* lin; long ldlin; const float* qexp; const float* bexp;
   float* cond_c; float* key_c; float* va_c; float* vb_c; float* afull_c; float* bfull_c; float* qk_c;
   const int* anc; const int* row_valid; const int* pos; const float* y_in; long ldyi; float* y; long ldy;
+  float* scratch;                 // [N][4*T*E floats + T ints]
   int N, T, d, E; float eps;
 };
 
-__global__ __launch_bounds__(256) void dynexp_step_kernel(DynParams p) {
+// scratch layout per sequence (floats): wfa[T][E] | wfb[T][E] | wba[T][E] | wbb[T][E] | slot[T] (int)
+__device__ __forceinline__ long dyn_scratch_stride(int T, int E) { return 4L * T * E + T; }
+
+// Kernel 1 (one block per sequence): cache writes, the 2t+E+1 dot products, all four normalised
+// weight tables → scratch.
+__global__ __launch_bounds__(256) void dynexp_scores_kernel(DynParams p) {
   extern __shared__ float sm[];
   const int d = p.d, E = p.E, n = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -88,6 +94,8 @@ __global__ __launch_bounds__(256) void dynexp_step_kernel(DynParams p) {
   const float* lin = p.lin + (long)n * p.ldlin;
   const float inv_sqrt_d = rsqrtf((float)d);
   const long NT = (long)p.N;
+  float* scr = p.scratch + (long)n * dyn_scratch_stride(p.T, E);
+  const int TE = p.T * E;
 
   for (int c = tid; c < d; c += 256) {
     const float cv = lin[c], kv = lin[d + c];
@@ -95,11 +103,15 @@ __global__ __launch_bounds__(256) void dynexp_step_kernel(DynParams p) {
     const long o = ((long)t * NT + n) * d + c;
     p.cond_c[o] = cv; p.key_c[o] = kv; p.va_c[o] = lin[2 * d + c]; p.vb_c[o] = lin[3 * d + c];
   }
-  for (int j = tid; j <= t; j += 256) slot[j] = j < t ? p.anc[(long)n * p.T + j] : n;
+  for (int j = tid; j <= t; j += 256) {
+    const int sl = j < t ? p.anc[(long)n * p.T + j] : n;
+    slot[j] = sl;
+    ((int*)(scr + 4 * TE))[j] = sl;
+  }
   __syncthreads();
 
-  // ---- dot products: one wave per item, lanes stride over d
-  //   items 0..E-1: qk_t[e];  E..E+t: dk[j] (j = item-E, 0..t);  E+t+1 .. E+2t: ck[j] (j = 0..t-1)
+  // dot products: one wave per item, lanes stride over d
+  //   items 0..E-1: qk_t[e];  E..E+t: dk[j] (j = 0..t);  E+t+1 .. E+2t: ck[j] (j = 0..t-1)
   const int nitems = E + (t + 1) + t;
   for (int it = wave; it < nitems; it += 4) {
     const float* a; const float* b;
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(256) void dynexp_step_kernel(DynParams p) {
   if (tid == 0) ck[t] = dk[t];           // cond_t·key_t
   __syncthreads();
 
-  // ---- forward normalisers: thread e sums over j
+  // forward normalisers (thread e sums over j) and backward normaliser (Σ over (j, e))
   if (tid < E) {
     float sp = 0.f, sn = 0.f;
     for (int j = 0; j <= t; ++j) {
@@ -135,7 +147,6 @@ __global__ __launch_bounds__(256) void dynexp_step_kernel(DynParams p) {
     nfw[tid] = 1.0f / (sp + p.eps);
     nfw[MAX_E + tid] = 1.0f / (sn + p.eps);
   }
-  // ---- backward normaliser: Σ over (j, e)
   float bp = 0.f, bn = 0.f;
   for (int i = tid; i < (t + 1) * E; i += 256) {
     const int j = i / E, e = i - j * E;
@@ -145,116 +156,155 @@ __global__ __launch_bounds__(256) void dynexp_step_kernel(DynParams p) {
   const float ibp = 1.0f / (block_sum(bp, red) + p.eps);
   const float ibn = 1.0f / (block_sum(bn, red) + p.eps);
   __syncthreads();
-
-  const int valid = p.row_valid[n];
-  // ---- per-channel accumulation (thread owns channels c = tid, tid+256, ...)
-  for (int c = tid; c < d; c += 256) {
-    float fa[MAX_E], fb[MAX_E];
-#pragma unroll
-    for (int e = 0; e < MAX_E; ++e) { fa[e] = 0.f; fb[e] = 0.f; }
-    for (int j = 0; j <= t; ++j) {
-      const long o = ((long)j * NT + slot[j]) * d + c;
-      const float va = j < t ? p.va_c[o] : lin[2 * d + c];
-      const float vb = j < t ? p.vb_c[o] : lin[3 * d + c];
-      const float dkj = dk[j];
-      const float* qkj = j < t ? p.qk_c + ((long)j * NT + slot[j]) * E : qk_t;
-#pragma unroll
-      for (int e = 0; e < MAX_E; ++e) {
-        if (e < E) {
-          const float z = (qkj[e] + dkj) * inv_sqrt_d;
-          fa[e] = fmaf(fmaxf(z, 0.f) * nfw[e], va, fa[e]);
-          fb[e] = fmaf(fmaxf(-z, 0.f) * nfw[MAX_E + e], vb, fb[e]);
-        }
-      }
-    }
-    const float cv = cond_t[c];
-    float oa = 0.f, ob = 0.f;
-    // newest position: afull/bfull straight from registers, and into the cache
-#pragma unroll
-    for (int e = 0; e < MAX_E; ++e) {
-      if (e < E) {
-        const float bias = p.bexp[(long)e * d + c] + cv;
-        const float af = fa[e] + bias, bf = fb[e] + bias;
-        const long o = (((long)t * NT + n) * E + e) * d + c;
-        p.afull_c[o] = af; p.bfull_c[o] = bf;
-        const float z = (qk_t[e] + ck[t]) * inv_sqrt_d;
-        oa = fmaf(fmaxf(z, 0.f) * ibp, af, oa);
-        ob = fmaf(fmaxf(-z, 0.f) * ibn, bf, ob);
-      }
-    }
-    for (int j = 0; j < t; ++j) {
-      const long base = (((long)j * NT + slot[j]) * E) * d + c;
-      const float ckj = ck[j];
-      for (int e = 0; e < E; ++e) {
-        const float z = (qk_t[e] + ckj) * inv_sqrt_d;
-        oa = fmaf(fmaxf(z, 0.f) * ibp, p.afull_c[base + (long)e * d], oa);
-        ob = fmaf(fmaxf(-z, 0.f) * ibn, p.bfull_c[base + (long)e * d], ob);
-      }
-    }
-    float yv = p.y_in[(long)n * p.ldyi + c];
-    if (valid) {
-      const float sg = 1.0f / (1.0f + expf(-lin[4 * d + c]));
-      yv += sg * oa + (1.0f - sg) * ob;
-    }
-    p.y[(long)n * p.ldy + c] = yv;
+  for (int i = tid; i < (t + 1) * E; i += 256) {
+    const int j = i / E, e = i - j * E;
+    const float q = j < t ? p.qk_c[((long)j * NT + slot[j]) * E + e] : qk_t[e];
+    const float zf = (q + dk[j]) * inv_sqrt_d;
+    const float zb = (qk_t[e] + ck[j]) * inv_sqrt_d;
+    scr[i] = fmaxf(zf, 0.f) * nfw[e];
+    scr[TE + i] = fmaxf(-zf, 0.f) * nfw[MAX_E + e];
+    scr[2 * TE + i] = fmaxf(zb, 0.f) * ibp;
+    scr[3 * TE + i] = fmaxf(-zb, 0.f) * ibn;
   }
 }
 
+// Kernel 2 (grid N x d/128, 128 threads, one channel per thread): the weighted sums over cached
+// class vectors.  All loads of one j are independent (2·E in flight per thread), coalesced over c.
+template <int EE>
+__global__ __launch_bounds__(128) void dynexp_accum_kernel(DynParams p) {
+  __shared__ float w[4 * MAX_T * EE];
+  __shared__ int slot[MAX_T];
+  const int d = p.d, n = blockIdx.x, tid = threadIdx.x;
+  const int c = blockIdx.y * 128 + tid;
+  const int t = *p.pos;
+  const long NT = (long)p.N;
+  const int TE = p.T * EE;
+  const float* scr = p.scratch + (long)n * dyn_scratch_stride(p.T, EE);
+  const int used = (t + 1) * EE;
+  for (int i = tid; i < used; i += 128) {
+    w[i] = scr[i]; w[MAX_T * EE + i] = scr[TE + i];
+    w[2 * MAX_T * EE + i] = scr[2 * TE + i]; w[3 * MAX_T * EE + i] = scr[3 * TE + i];
+  }
+  for (int j = tid; j <= t; j += 128) slot[j] = ((const int*)(scr + 4 * TE))[j];
+  __syncthreads();
+  if (c >= d) return;
+  const float* wfa = w; const float* wfb = w + MAX_T * EE;
+  const float* wba = w + 2 * MAX_T * EE; const float* wbb = w + 3 * MAX_T * EE;
+  const float* lin = p.lin + (long)n * p.ldlin;
+
+  float fa[EE], fb[EE];
+#pragma unroll
+  for (int e = 0; e < EE; ++e) { fa[e] = 0.f; fb[e] = 0.f; }
+  for (int j = 0; j <= t; ++j) {
+    const long o = ((long)j * NT + slot[j]) * d + c;
+    const float va = j < t ? p.va_c[o] : lin[2 * d + c];
+    const float vb = j < t ? p.vb_c[o] : lin[3 * d + c];
+#pragma unroll
+    for (int e = 0; e < EE; ++e) {
+      fa[e] = fmaf(wfa[j * EE + e], va, fa[e]);
+      fb[e] = fmaf(wfb[j * EE + e], vb, fb[e]);
+    }
+  }
+  const float cv = lin[c];
+  float oa = 0.f, ob = 0.f;
+#pragma unroll
+  for (int e = 0; e < EE; ++e) {
+    const float bias = p.bexp[(long)e * d + c] + cv;
+    const float af = fa[e] + bias, bf = fb[e] + bias;
+    const long o = (((long)t * NT + n) * EE + e) * d + c;
+    p.afull_c[o] = af; p.bfull_c[o] = bf;
+    oa = fmaf(wba[t * EE + e], af, oa);
+    ob = fmaf(wbb[t * EE + e], bf, ob);
+  }
+  for (int j = 0; j < t; ++j) {
+    const long base = (((long)j * NT + slot[j]) * EE) * d + c;
+    float av[EE], bv[EE];
+#pragma unroll
+    for (int e = 0; e < EE; ++e) { av[e] = p.afull_c[base + (long)e * d]; bv[e] = p.bfull_c[base + (long)e * d]; }
+#pragma unroll
+    for (int e = 0; e < EE; ++e) {
+      oa = fmaf(wba[j * EE + e], av[e], oa);
+      ob = fmaf(wbb[j * EE + e], bv[e], ob);
+    }
+  }
+  float yv = p.y_in[(long)n * p.ldyi + c];
+  if (p.row_valid[n]) {
+    const float sg = 1.0f / (1.0f + expf(-lin[4 * d + c]));
+    yv += sg * oa + (1.0f - sg) * ob;
+  }
+  p.y[(long)n * p.ldy + c] = yv;
+}
+
 // ---------------------------------------------------------------------------------------------
-// One block per sequence.  kv: [n_img, S, ldkv] with K at column koff and V at column voff.
+// Cross attention: one wave per (sequence, head).  kv: [n_img, S, ldkv], K at koff, V at voff.
+//   scores : dk/16 lanes per key (16 floats each), 64/(dk/16) keys per sweep, xor-shuffle reduce
+//   softmax: lanes stride over S
+//   P·V    : lane = channel of the head, coalesced dk·4-byte rows, 8 keys in flight
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __restrict__ q, long ldq,
-                                                              const float* __restrict__ kv, long ldkv, int koff,
-                                                              int voff, const int* __restrict__ enc_len,
-                                                              const int* __restrict__ row_valid,
-                                                              float* __restrict__ out, long ldo, int beams, int S,
-                                                              int d, int heads) {
-  extern __shared__ float sm[];
-  float* qs = sm;                 // [d]
-  float* sc = qs + d;             // [heads][S]
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(64) void cross_attn_step_kernel(const float* __restrict__ q, long ldq,
+                                                             const float* __restrict__ kv, long ldkv, int koff,
+                                                             int voff, const int* __restrict__ enc_len,
+                                                             const int* __restrict__ row_valid,
+                                                             float* __restrict__ out, long ldo, int beams, int S,
+                                                             int d, int heads) {
+  extern __shared__ float sc[];          // [S]
+  const int n = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
   const int img = n / beams;
   const int dk = d / heads;
+  const int lpk = dk >> 4;               // lanes per key (1, 2 or 4)
+  const int kps = 64 / lpk;              // keys per sweep
   const int len = enc_len[img];
   const int valid = row_valid[n];
   const float inv = rsqrtf((float)dk);
   const float* kvb = kv + (long)img * S * ldkv;
-  for (int c = tid; c < d; c += 256) qs[c] = q[(long)n * ldq + c];
-  __syncthreads();
+  const int part = lane % lpk, kslot = lane / lpk;
 
-  // scores: wave per key; lane owns a contiguous run of `per` channels, a head spans dk/per lanes
-  const int per = d / 64;                 // d % 64 == 0 (checked on the host), per divides dk
-  const int lanes_per_head = dk / per;
-  for (int s = wave; s < S; s += 4) {
-    const float* kr = kvb + (long)s * ldkv + koff + lane * per;
+  float4 qv[4];
+  {
+    const float* qp = q + (long)n * ldq + h * dk + part * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qv[i] = *(const float4*)(qp + 4 * i);
+  }
+  for (int s0 = 0; s0 < S; s0 += kps) {
+    const int s = s0 + kslot;
     float acc = 0.f;
-    for (int i = 0; i < per; ++i) acc = fmaf(qs[lane * per + i], kr[i], acc);
-    for (int o = 1; o < lanes_per_head; o <<= 1) acc += __shfl_xor(acc, o, 64);
-    if ((lane % lanes_per_head) == 0) {
-      const int h = lane / lanes_per_head;
+    if (s < S) {
+      const float* kr = kvb + (long)s * ldkv + koff + h * dk + part * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 k4 = *(const float4*)(kr + 4 * i);
+        acc = fmaf(qv[i].x, k4.x, acc); acc = fmaf(qv[i].y, k4.y, acc);
+        acc = fmaf(qv[i].z, k4.z, acc); acc = fmaf(qv[i].w, k4.w, acc);
+      }
+    }
+    for (int o = 1; o < lpk; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (part == 0 && s < S) {
       float v = acc * inv;
       if (!valid || s >= len) v = -1e4f;      // masked_fill(mask == 0, -1e4), layers.py:286
-      sc[h * S + s] = v;
+      sc[s] = v;
     }
   }
   __syncthreads();
-  // softmax per head: wave w handles heads w, w+4, ...
-  for (int h = wave; h < heads; h += 4) {
-    float m = -INFINITY;
-    for (int s = lane; s < S; s += 64) m = fmaxf(m, sc[h * S + s]);
-    m = wave_max(m);
-    float l = 0.f;
-    for (int s = lane; s < S; s += 64) { const float e = expf(sc[h * S + s] - m); sc[h * S + s] = e; l += e; }
-    l = wave_sum(l);
-    const float il = 1.0f / l;
-    for (int s = lane; s < S; s += 64) sc[h * S + s] *= il;
-  }
+  float m = -INFINITY;
+  for (int s = lane; s < S; s += 64) m = fmaxf(m, sc[s]);
+  m = wave_max(m);
+  float l = 0.f;
+  for (int s = lane; s < S; s += 64) { const float e = expf(sc[s] - m); sc[s] = e; l += e; }
+  l = wave_sum(l);
   __syncthreads();
-  for (int c = tid; c < d; c += 256) {
-    const int h = c / dk;
+  if (lane < dk) {
+    const float* vp = kvb + voff + h * dk + lane;
     float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc = fmaf(sc[h * S + s], kvb[(long)s * ldkv + voff + c], acc);
-    out[(long)n * ldo + c] = acc;
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = vp[(long)(s + i) * ldkv];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = fmaf(sc[s + i], v[i], acc);
+    }
+    for (; s < S; ++s) acc = fmaf(sc[s], vp[(long)s * ldkv], acc);
+    out[(long)n * ldo + h * dk + lane] = acc / l;
   }
 }
 
@@ -457,17 +507,27 @@ extern "C" int odic_dynexp_step(const float* lin, int64_t ldlin, const float* qe
                                 float* cond_c, float* key_c, float* va_c, float* vb_c, float* afull_c,
                                 float* bfull_c, float* qk_c, const int32_t* anc, const int32_t* row_valid,
                                 const int32_t* pos, const float* y_in, int64_t ldy_in, float* y, int64_t ldy,
-                                int32_t N, int32_t T, int32_t d, int32_t E, float eps, void* stream) {
+                                float* scratch, int32_t N, int32_t T, int32_t d, int32_t E, float eps, void* stream) {
   if (!lin || !qexp || !bexp || !cond_c || !key_c || !va_c || !vb_c || !afull_c || !bfull_c || !qk_c || !anc ||
-      !row_valid || !pos || !y || !y_in)
+      !row_valid || !pos || !y || !y_in || !scratch)
     return ODIC_ENULL;
   if (N <= 0 || T <= 0 || T > MAX_T || d <= 0 || E <= 0 || E > MAX_E) return ODIC_EINVAL;
+  if (E != 4 && E != 8 && E != 16 && E != 32) return ODIC_EUNSUPPORTED;
   DynParams p;
   p.lin = lin; p.ldlin = ldlin; p.qexp = qexp; p.bexp = bexp; p.cond_c = cond_c; p.key_c = key_c; p.va_c = va_c;
   p.vb_c = vb_c; p.afull_c = afull_c; p.bfull_c = bfull_c; p.qk_c = qk_c; p.anc = anc; p.row_valid = row_valid;
-  p.pos = pos; p.y_in = y_in; p.ldyi = ldy_in; p.y = y; p.ldy = ldy; p.N = N; p.T = T; p.d = d; p.E = E; p.eps = eps;
+  p.pos = pos; p.y_in = y_in; p.ldyi = ldy_in; p.y = y; p.ldy = ldy; p.scratch = scratch;
+  p.N = N; p.T = T; p.d = d; p.E = E; p.eps = eps;
+  hipStream_t s = (hipStream_t)stream;
   const size_t shmem = (size_t)(2 * d + 2 * MAX_T + MAX_E + 2 * MAX_E + 8) * sizeof(float) + MAX_T * sizeof(int);
-  hipLaunchKernelGGL(dynexp_step_kernel, dim3(N), dim3(256), shmem, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(dynexp_scores_kernel, dim3(N), dim3(256), shmem, s, p);
+  dim3 grid(N, (d + 127) / 128);
+  switch (E) {
+    case 4: hipLaunchKernelGGL(dynexp_accum_kernel<4>, grid, dim3(128), 0, s, p); break;
+    case 8: hipLaunchKernelGGL(dynexp_accum_kernel<8>, grid, dim3(128), 0, s, p); break;
+    case 16: hipLaunchKernelGGL(dynexp_accum_kernel<16>, grid, dim3(128), 0, s, p); break;
+    default: hipLaunchKernelGGL(dynexp_accum_kernel<32>, grid, dim3(128), 0, s, p); break;
+  }
   return odic_launch_status();
 }
 
@@ -476,15 +536,14 @@ extern "C" int odic_cross_attn_step(const float* q, int64_t ldq, const float* kv
                                     int64_t ldo, int32_t N, int32_t n_img, int32_t S, int32_t d, int32_t heads,
                                     void* stream) {
   if (!q || !kv || !enc_len || !row_valid || !out) return ODIC_ENULL;
-  if (N <= 0 || n_img <= 0 || N % n_img || S <= 0 || d <= 0 || heads <= 0 || d % heads || d % 64) return ODIC_EINVAL;
-  const int dk = d / heads, per = d / 64;
-  if (dk % per) return ODIC_EINVAL;
-  const int lph = dk / per;
-  if (lph & (lph - 1)) return ODIC_EINVAL;            // xor-shuffle reduction needs a power of two
-  const size_t shmem = (size_t)(d + heads * S) * sizeof(float);
-  if (shmem > 64 * 1024) return ODIC_EINVAL;
-  hipLaunchKernelGGL(cross_attn_step_kernel, dim3(N), dim3(256), shmem, (hipStream_t)stream, q, (long)ldq, kv,
-                     (long)ldkv, koff, voff, enc_len, row_valid, out, (long)ldo, N / n_img, S, d, heads);
+  if (N <= 0 || n_img <= 0 || N % n_img || S <= 0 || d <= 0 || heads <= 0 || d % heads) return ODIC_EINVAL;
+  const int dk = d / heads;
+  if (dk != 16 && dk != 32 && dk != 64) return ODIC_EUNSUPPORTED;
+  if ((ldq & 3) || (ldkv & 3) || (koff & 3) || ((uintptr_t)q & 15) || ((uintptr_t)kv & 15)) return ODIC_EINVAL;
+  if (S > 8192) return ODIC_EINVAL;
+  hipLaunchKernelGGL(cross_attn_step_kernel, dim3(N, heads), dim3(64), (size_t)S * sizeof(float),
+                     (hipStream_t)stream, q, (long)ldq, kv, (long)ldkv, koff, voff, enc_len, row_valid, out,
+                     (long)ldo, N / n_img, S, d, heads);
   return odic_launch_status();
 }
 

@@ -119,6 +119,100 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(Params p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Skinny-M variant (decoder steps: M = images x beams = 48..192 rows against 0.25-20 MB weights).
+// These products are weight-streaming and latency-bound, so the grid is cut for parallelism:
+//   * one block per 16 output columns, every block covers ALL M rows (MT = ceil(M/16) MFMA tiles);
+//   * the block's waves split K between them (in-block split-K), each wave streams its K-slice of
+//     the 16 W rows straight from global memory into MFMA operands (no LDS round trip: W is read
+//     once, A is L2-resident) as float4 loads = 4 MFMA K-steps per load;
+//   * partial accumulators are summed through LDS, then the usual epilogue.
+// K-order inside an MFMA is permuted (slot (kq, s) ↔ k = k0 + 4·kq + s) identically on both
+// operands, which only changes the summation order.
+// ---------------------------------------------------------------------------------------------
+template <int MT, typename OutT>
+__global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int kslice) {
+  extern __shared__ float red[];                   // [nwaves][MT][4][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int n0 = blockIdx.x * 16;
+  const long bz = blockIdx.z;
+  const float* A = p.A + bz * p.strideA;
+  const float* W = p.W + bz * p.strideW;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int k_begin = wave * kslice, k_end = min(p.K, k_begin + kslice);
+
+  f32x4_t acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const bool wn_ok = (n0 + fr) < p.N;
+  const float* wrow = W + (long)min(n0 + fr, p.N - 1) * p.ldw + 4 * fq;
+  const float* arow[MT];
+  bool am_ok[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = i * 16 + fr;
+    am_ok[i] = m < p.M;
+    arow[i] = A + (long)min(m, p.M - 1) * p.lda + 4 * fq;
+  }
+  for (int k = k_begin; k < k_end; k += 16) {
+    float4 w4 = *(const float4*)(wrow + k);
+    if (!wn_ok) w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a4[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      a4[i] = *(const float4*)(arow[i] + k);
+      if (!am_ok[i]) a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].x, w4.x, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].y, w4.y, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].z, w4.z, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].w, w4.w, acc[i], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[((wave * MT + i) * 4 + j) * 64 + lane] = acc[i][j];
+  __syncthreads();
+
+  const float* bias = p.bias ? p.bias + bz * p.strideBias : nullptr;
+  const float* resid = p.residual ? p.residual + bz * p.strideR : nullptr;
+  OutT* out = (OutT*)p.out + bz * p.strideC;
+  for (int e = tid; e < MT * 256; e += blockDim.x) {
+    const int i = e >> 8, j = (e >> 6) & 3, l = e & 63;
+    float v = 0.f;
+    for (int w = 0; w < nwaves; ++w) v += red[((w * MT + i) * 4 + j) * 64 + l];
+    const int row = i * 16 + (l >> 4) * 4 + j, col = n0 + (l & 15);
+    if (row < p.M && col < p.N) {
+      v *= p.alpha;
+      if (bias) v += p.bias_axis ? bias[row] : bias[col];
+      v = apply_act<false>(v, p.act);
+      if (resid) v += resid[(long)row * p.ldr + col];
+      store_from_f32<OutT>(out + (long)row * p.ldc + col, v);
+    }
+  }
+}
+
+template <int MT>
+static void launch_skinny(const Params& p, int out_dtype, int batch, hipStream_t stream) {
+  // waves: aim at K-slices of ~128, at most 16 waves, LDS for the reduction <= 48 KiB
+  int nw = (p.K + 127) / 128;
+  if (nw > 16) nw = 16;
+  while (nw > 1 && nw * MT > 48) --nw;
+  if (nw < 1) nw = 1;
+  int kslice = ((p.K + nw - 1) / nw + 15) / 16 * 16;
+  dim3 grid((p.N + 15) / 16, 1, batch), block(64 * nw);
+  const size_t shmem = (size_t)nw * MT * 256 * sizeof(float);
+  if (out_dtype == ODIC_BF16)
+    hipLaunchKernelGGL((gemm_f32_skinny_kernel<MT, bf16_raw>), grid, block, shmem, stream, p, kslice);
+  else
+    hipLaunchKernelGGL((gemm_f32_skinny_kernel<MT, float>), grid, block, shmem, stream, p, kslice);
+}
+
 }  // namespace
 
 int odic_gemm_f32_launch(const odic_gemm_args* a, hipStream_t stream) {
@@ -131,6 +225,17 @@ int odic_gemm_f32_launch(const odic_gemm_args* a, hipStream_t stream) {
   p.alpha = a->alpha; p.act = a->act; p.bias_axis = a->bias_axis;
   p.vec_ok = (a->lda % 4 == 0) && (a->ldw % 4 == 0) && (a->strideA % 4 == 0) && (a->strideW % 4 == 0) &&
              (((uintptr_t)a->A & 15) == 0) && (((uintptr_t)a->W & 15) == 0);
+  if (p.vec_ok && a->M <= 192 && a->K % 16 == 0 && a->N >= 64) {
+    const int mt = (a->M + 15) / 16;
+    if (mt <= 1) launch_skinny<1>(p, a->out_dtype, a->batch, stream);
+    else if (mt <= 2) launch_skinny<2>(p, a->out_dtype, a->batch, stream);
+    else if (mt <= 3) launch_skinny<3>(p, a->out_dtype, a->batch, stream);
+    else if (mt <= 4) launch_skinny<4>(p, a->out_dtype, a->batch, stream);
+    else if (mt <= 6) launch_skinny<6>(p, a->out_dtype, a->batch, stream);
+    else if (mt <= 9) launch_skinny<9>(p, a->out_dtype, a->batch, stream);
+    else launch_skinny<12>(p, a->out_dtype, a->batch, stream);
+    return odic_launch_status();
+  }
   dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM, a->batch);
   if (grid.y > 65535) return ODIC_EINVAL;
   if (a->out_dtype == ODIC_BF16)

@@ -123,6 +123,7 @@ class DecodeState:
         self.caches = [dict(cond=f(T, N, d), key=f(T, N, d), va=f(T, N, d), vb=f(T, N, d),
                             afull=f(T, N, E, d), bfull=f(T, N, E, d), qk=f(T, N, E)) for _ in range(L)]
         self.anc = i32(N, T)
+        self.dyn_scratch = f(N, 4 * T * E + T)
         self.row_valid = torch.ones(N, dtype=torch.int32, device=dv)
         self.next_tok = torch.zeros(N, dtype=torch.int64, device=dv)
         self.pos, self.done = i32(1), i32(1)
@@ -266,7 +267,7 @@ class CaptionerEngine:
             x2 = ops.layernorm(xin, w["n1w"], w["n1b"], M=N, C_=d, ldx=ld)
             lin = ops.gemm(x2, w["dyn_w"], w["dyn_b"])                                       # [N,5d]
             ops.dynexp_step(lin, 5 * d, w["qexp"], w["bexp"], c["cond"], c["key"], c["va"], c["vb"], c["afull"],
-                            c["bfull"], c["qk"], st.anc, st.row_valid, st.pos, xin, ld, xo, ld, N, st.T, d,
+                            c["bfull"], c["qk"], st.anc, st.row_valid, st.pos, xin, ld, xo, ld, st.dyn_scratch, N, st.T, d,
                             g.num_exp_dec)
             x2 = ops.layernorm(xo, w["n2w"], w["n2b"], M=N, C_=d, ldx=ld)
             q = ops.gemm(x2, w["wq"], w["bq"])
