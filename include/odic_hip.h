@@ -204,6 +204,7 @@ typedef struct odic_beam_state {
   int64_t* tokens; float* logprobs; int32_t* anc;
   float* cumul; int32_t* n_elem; int32_t* has_eos; int32_t* row_valid; int64_t* next_tok;
   int32_t* pos; int32_t* done;
+  int32_t* ctr;      /* int32 scalar, zero before the first call: inter-block arrival counter */
 } odic_beam_state;
 int odic_beam_step(const float* cand_val, const int32_t* cand_idx, const odic_beam_state* st,
                    int32_t n_img, int32_t beams, int32_t T, int64_t eos_idx, void* stream);

@@ -35,7 +35,7 @@ class GemmArgs(C.Structure):
 class BeamState(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("tokens", "logprobs", "anc", "cumul", "n_elem", "has_eos", "row_valid", "next_tok",
-                 "pos", "done")]
+                 "pos", "done", "ctr")]
 
 
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float

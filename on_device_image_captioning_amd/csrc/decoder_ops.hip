@@ -75,12 +75,11 @@ struct DynParams {
 // scratch layout per sequence (floats): wfa[T][E] | wfb[T][E] | wba[T][E] | wbb[T][E] | slot[T] (int)
 __device__ __forceinline__ long dyn_scratch_stride(int T, int E) { return 4L * T * E + T; }
 
-// Kernel 1 (one block per sequence): cache writes, the 2t+E+1 dot products, all four normalised
-// weight tables → scratch.
-__global__ __launch_bounds__(256) void dynexp_scores_kernel(DynParams p) {
-  extern __shared__ float sm[];
+// Kernel 1 (one block per sequence, 512 threads): cache writes, the 2t+E+1 dot products (one per
+// 16-lane group, 32 in flight per block, float4 loads), all four normalised weight tables → scratch.
+__global__ __launch_bounds__(512) void dynexp_scores_kernel(DynParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int d = p.d, E = p.E, n = blockIdx.x, tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
   const int t = *p.pos;
   float* cond_t = sm;                  // [d]
   float* key_t = cond_t + d;           // [d]
@@ -90,6 +89,7 @@ __global__ __launch_bounds__(256) void dynexp_scores_kernel(DynParams p) {
   float* nfw = qk_t + MAX_E;           // [2*MAX_E] 1/(Σ_j relu(±z_fw[e][·]) + eps)
   float* red = nfw + 2 * MAX_E;        // [8]
   int* slot = (int*)(red + 8);         // [MAX_T]
+  float* qkh = (float*)(slot + MAX_T); // [MAX_T*E]  qexp[e]·key_j history
 
   const float* lin = p.lin + (long)n * p.ldlin;
   const float inv_sqrt_d = rsqrtf((float)d);
@@ -97,23 +97,28 @@ __global__ __launch_bounds__(256) void dynexp_scores_kernel(DynParams p) {
   float* scr = p.scratch + (long)n * dyn_scratch_stride(p.T, E);
   const int TE = p.T * E;
 
-  for (int c = tid; c < d; c += 256) {
+  for (int c = tid; c < d; c += 512) {
     const float cv = lin[c], kv = lin[d + c];
     cond_t[c] = cv; key_t[c] = kv;
     const long o = ((long)t * NT + n) * d + c;
     p.cond_c[o] = cv; p.key_c[o] = kv; p.va_c[o] = lin[2 * d + c]; p.vb_c[o] = lin[3 * d + c];
   }
-  for (int j = tid; j <= t; j += 256) {
+  for (int j = tid; j <= t; j += 512) {
     const int sl = j < t ? p.anc[(long)n * p.T + j] : n;
     slot[j] = sl;
     ((int*)(scr + 4 * TE))[j] = sl;
   }
   __syncthreads();
+  for (int i = tid; i < t * E; i += 512) {
+    const int j = i / E, e = i - j * E;
+    qkh[i] = p.qk_c[((long)j * NT + slot[j]) * E + e];
+  }
 
-  // dot products: one wave per item, lanes stride over d
+  // dot products, one per 16-lane group:
   //   items 0..E-1: qk_t[e];  E..E+t: dk[j] (j = 0..t);  E+t+1 .. E+2t: ck[j] (j = 0..t-1)
   const int nitems = E + (t + 1) + t;
-  for (int it = wave; it < nitems; it += 4) {
+  const int grp = tid >> 4, gl = tid & 15;
+  for (int it = grp; it < nitems; it += 32) {
     const float* a; const float* b;
     if (it < E) { a = p.qexp + (long)it * d; b = key_t; }
     else if (it < E + t + 1) {
@@ -124,9 +129,13 @@ __global__ __launch_bounds__(256) void dynexp_scores_kernel(DynParams p) {
       a = p.cond_c + ((long)j * NT + slot[j]) * d; b = key_t;
     }
     float s = 0.f;
-    for (int c = lane; c < d; c += 64) s = fmaf(a[c], b[c], s);
-    s = wave_sum(s);
-    if (lane == 0) {
+    for (int c = gl * 4; c < d; c += 64) {
+      const float4 av = *(const float4*)(a + c);
+      const float4 bv = *(const float4*)(b + c);
+      s = fmaf(av.x, bv.x, s); s = fmaf(av.y, bv.y, s); s = fmaf(av.z, bv.z, s); s = fmaf(av.w, bv.w, s);
+    }
+    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+    if (gl == 0) {
       if (it < E) { qk_t[it] = s; p.qk_c[((long)t * NT + n) * E + it] = s; }
       else if (it < E + t + 1) dk[it - E] = s;
       else ck[it - E - t - 1] = s;
@@ -136,11 +145,10 @@ __global__ __launch_bounds__(256) void dynexp_scores_kernel(DynParams p) {
   if (tid == 0) ck[t] = dk[t];           // cond_t·key_t
   __syncthreads();
 
-  // forward normalisers (thread e sums over j) and backward normaliser (Σ over (j, e))
   if (tid < E) {
     float sp = 0.f, sn = 0.f;
     for (int j = 0; j <= t; ++j) {
-      const float q = j < t ? p.qk_c[((long)j * NT + slot[j]) * E + tid] : qk_t[tid];
+      const float q = j < t ? qkh[j * E + tid] : qk_t[tid];
       const float z = (q + dk[j]) * inv_sqrt_d;
       sp += fmaxf(z, 0.f); sn += fmaxf(-z, 0.f);
     }
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256) void dynexp_scores_kernel(DynParams p) {
     nfw[MAX_E + tid] = 1.0f / (sn + p.eps);
   }
   float bp = 0.f, bn = 0.f;
-  for (int i = tid; i < (t + 1) * E; i += 256) {
+  for (int i = tid; i < (t + 1) * E; i += 512) {
     const int j = i / E, e = i - j * E;
     const float z = (qk_t[e] + ck[j]) * inv_sqrt_d;
     bp += fmaxf(z, 0.f); bn += fmaxf(-z, 0.f);
@@ -156,9 +164,9 @@ __global__ __launch_bounds__(256) void dynexp_scores_kernel(DynParams p) {
   const float ibp = 1.0f / (block_sum(bp, red) + p.eps);
   const float ibn = 1.0f / (block_sum(bn, red) + p.eps);
   __syncthreads();
-  for (int i = tid; i < (t + 1) * E; i += 256) {
+  for (int i = tid; i < (t + 1) * E; i += 512) {
     const int j = i / E, e = i - j * E;
-    const float q = j < t ? p.qk_c[((long)j * NT + slot[j]) * E + e] : qk_t[e];
+    const float q = j < t ? qkh[i] : qk_t[e];
     const float zf = (q + dk[j]) * inv_sqrt_d;
     const float zb = (qk_t[e] + ck[j]) * inv_sqrt_d;
     scr[i] = fmaxf(zf, 0.f) * nfw[e];
@@ -309,35 +317,43 @@ __global__ __launch_bounds__(64) void cross_attn_step_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// One block per row: max, log-sum-exp, then k rounds of block arg-max (ties → lower index).
+// One block (1024 threads) per row.  Pass 1: every thread keeps the top-KM of its strided slice in
+// registers (insertion into a static array) → the row max is the max of the heads.  Pass 2:
+// Σ exp(x - max).  Then k rounds of block arg-max over the thread heads; the winner pops its
+// head.  Ties → lower index (within a thread indices ascend, across threads compared explicitly).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __restrict__ logits, long ldl,
-                                                              float* __restrict__ logp_out, long ldp,
-                                                              float* __restrict__ top_val, int* __restrict__ top_idx,
-                                                              int V, int k) {
-  __shared__ float red[8];
-  __shared__ float bv[4];
-  __shared__ int bi[4];
-  __shared__ int taken[MAX_K];
+template <int KM>
+__global__ __launch_bounds__(1024) void logsoftmax_topk_kernel(const float* __restrict__ logits, long ldl,
+                                                               float* __restrict__ logp_out, long ldp,
+                                                               float* __restrict__ top_val, int* __restrict__ top_idx,
+                                                               int V, int k) {
+  __shared__ float red[16];
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  __shared__ int winner;
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* x = logits + (long)n * ldl;
-  float m = -INFINITY;
-  for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
-  m = block_max(m, red);
+  float tv[KM]; int ti[KM];
+#pragma unroll
+  for (int q = 0; q < KM; ++q) { tv[q] = -INFINITY; ti[q] = 0x7fffffff; }
+  for (int i = tid; i < V; i += 1024) {
+    float v = x[i]; int vi = i;
+    if (v > tv[KM - 1]) {
+#pragma unroll
+      for (int q = 0; q < KM; ++q) {
+        if (v > tv[q]) { const float fv = tv[q]; const int fi = ti[q]; tv[q] = v; ti[q] = vi; v = fv; vi = fi; }
+      }
+    }
+  }
+  const float m = block_max(tv[0], red);
   float s = 0.f;
-  for (int i = tid; i < V; i += 256) s += expf(x[i] - m);
+  for (int i = tid; i < V; i += 1024) s += expf(x[i] - m);
   s = block_sum(s, red);
   const float lse = m + logf(s);
   if (logp_out)
-    for (int i = tid; i < V; i += 256) logp_out[(long)n * ldp + i] = x[i] - lse;
+    for (int i = tid; i < V; i += 1024) logp_out[(long)n * ldp + i] = x[i] - lse;
   for (int r = 0; r < k; ++r) {
-    float best = -INFINITY; int besti = 0x7fffffff;
-    for (int i = tid; i < V; i += 256) {
-      bool skip = false;
-      for (int q = 0; q < r; ++q) skip |= (taken[q] == i);
-      const float v = x[i];
-      if (!skip && (v > best || (v == best && i < besti))) { best = v; besti = i; }
-    }
+    float best = tv[0]; int besti = ti[0];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(best, o, 64);
@@ -348,132 +364,128 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __res
     __syncthreads();
     if (tid == 0) {
       float b = bv[0]; int ix = bi[0];
-      for (int w = 1; w < 4; ++w)
+      for (int w = 1; w < 16; ++w)
         if (bv[w] > b || (bv[w] == b && bi[w] < ix)) { b = bv[w]; ix = bi[w]; }
-      taken[r] = ix;
+      winner = ix;
       top_val[(long)n * k + r] = b - lse;
       top_idx[(long)n * k + r] = ix;
     }
     __syncthreads();
+    if (ti[0] == winner) {                 // pop (static shifts keep the array in registers)
+#pragma unroll
+      for (int q = 0; q + 1 < KM; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
+      tv[KM - 1] = -INFINITY; ti[KM - 1] = 0x7fffffff;
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Beam bookkeeping: ONE block; image b is handled by wave (b & 3) in round (b >> 2).  All waves run
-// the same number of rounds so the block barriers are uniform.  The prefix / log-prob / ancestor
-// rows of an image are permuted IN PLACE: a lane owns whole columns j, reads the k parent values
-// of its column first and then writes the k new rows.
+// Beam bookkeeping: one 64-lane block per image.  Lane 0 does the k·k selection, all lanes permute
+// the prefix / log-prob / ancestor rows IN PLACE (a lane owns whole columns j: it reads the k parent
+// values of its column first, then writes the k new rows).  The block that arrives last at `ctr`
+// (low 16 bits = arrivals, high bits = images with a still-growing beam) advances *pos, raises
+// *done when nothing grows any more, and re-arms the counter.
 // ---------------------------------------------------------------------------------------------
 struct BeamParams {
   const float* cand_val; const int* cand_idx;
   long long* tok; float* lp; int* anc;
   float* cumul; int* n_elem; int* has_eos; int* row_valid; long long* next_tok;
-  int* pos; int* done;
+  int* pos; int* done; int* ctr;
   int n_img, k, T; long long eos;
 };
 
-__global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
-  __shared__ int s_parent[4][MAX_K];
-  __shared__ int s_word[4][MAX_K];
-  __shared__ float s_lp[4][MAX_K];
-  __shared__ float s_cumul[4][MAX_K];
-  __shared__ int s_alive[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(64) void beam_step_kernel(BeamParams p) {
+  __shared__ int s_parent[MAX_K];
+  __shared__ int s_word[MAX_K];
+  __shared__ float s_lp[MAX_K];
+  __shared__ float s_cumul[MAX_K];
+  const int lane = threadIdx.x, b = blockIdx.x;
   const int k = p.k, T = p.T;
   const int t = *p.pos;                 // position just processed; prefix length is t+1
   int alive_any = 0;
 
-  for (int b0 = 0; b0 < p.n_img; b0 += 4) {
-    const int b = b0 + wave;
-    const bool active = b < p.n_img;
-    // ---- selection (lane 0): top-k of the k·k masked totals (first step: the k seeds of beam 0)
-    if (active && lane == 0) {
-      if (t == 0) {
-        for (int r = 0; r < k; ++r) {
-          s_parent[wave][r] = 0;
-          s_word[wave][r] = p.cand_idx[((long)b * k) * k + r];
-          s_lp[wave][r] = p.cand_val[((long)b * k) * k + r];
-        }
-      } else {
-        float tot[MAX_K * MAX_K];
-        for (int j = 0; j < k; ++j) {
-          const int dn = p.has_eos[b * k + j];
-          const float cu = p.cumul[b * k + j];
-          for (int c = 0; c < k; ++c) {
-            const float v = dn ? (c == 0 ? 0.0f : -999.0f) : p.cand_val[((long)b * k + j) * k + c];
-            tot[j * k + c] = cu + v;
-          }
-        }
-        for (int r = 0; r < k; ++r) {
-          int bi = 0; float bvv = -INFINITY;
-          for (int i = 0; i < k * k; ++i)
-            if (tot[i] > bvv) { bvv = tot[i]; bi = i; }
-          tot[bi] = -INFINITY;
-          const int j = bi / k, c = bi - j * k;
-          const int dn = p.has_eos[b * k + j];
-          s_parent[wave][r] = j;
-          s_word[wave][r] = p.cand_idx[((long)b * k + j) * k + c];
-          s_lp[wave][r] = dn ? (c == 0 ? 0.0f : -999.0f) : p.cand_val[((long)b * k + j) * k + c];
-        }
-      }
-      // cumulative score = re-summed per-token log-probs of the parent prefix + the new one (:213)
+  if (lane == 0) {
+    if (t == 0) {                       // seeding: the k best words of beam 0
       for (int r = 0; r < k; ++r) {
-        const long src = ((long)b * k + s_parent[wave][r]) * T;
-        float cs = 0.f;
-        for (int j = 0; j <= t; ++j) cs += p.lp[src + j];
-        s_cumul[wave][r] = cs + s_lp[wave][r];
+        s_parent[r] = 0;
+        s_word[r] = p.cand_idx[((long)b * k) * k + r];
+        s_lp[r] = p.cand_val[((long)b * k) * k + r];
+      }
+    } else {
+      float tot[MAX_K * MAX_K];
+      for (int j = 0; j < k; ++j) {
+        const int dn = p.has_eos[b * k + j];
+        const float cu = p.cumul[b * k + j];
+        for (int c = 0; c < k; ++c) {
+          const float v = dn ? (c == 0 ? 0.0f : -999.0f) : p.cand_val[((long)b * k + j) * k + c];
+          tot[j * k + c] = cu + v;
+        }
+      }
+      for (int r = 0; r < k; ++r) {
+        int bi = 0; float bvv = -INFINITY;
+        for (int i = 0; i < k * k; ++i)
+          if (tot[i] > bvv) { bvv = tot[i]; bi = i; }
+        tot[bi] = -INFINITY;
+        const int j = bi / k, c = bi - j * k;
+        const int dn = p.has_eos[b * k + j];
+        s_parent[r] = j;
+        s_word[r] = p.cand_idx[((long)b * k + j) * k + c];
+        s_lp[r] = dn ? (c == 0 ? 0.0f : -999.0f) : p.cand_val[((long)b * k + j) * k + c];
       }
     }
-    __syncthreads();
-    if (active) {
-      // ---- in-place column-wise permutation of the k rows, then append the new word
-      const long base = (long)b * k * T;
-      for (int j = lane; j <= t; j += 64) {
-        long long tv[MAX_K]; float lv[MAX_K]; int av[MAX_K];
-#pragma unroll
-        for (int r = 0; r < MAX_K; ++r) {
-          if (r < k) {
-            const long src = base + (long)s_parent[wave][r] * T + j;
-            tv[r] = p.tok[src]; lv[r] = p.lp[src];
-            av[r] = j < t ? p.anc[src] : b * k + s_parent[wave][r];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < MAX_K; ++r) {
-          if (r < k) {
-            const long dst = base + (long)r * T + j;
-            p.tok[dst] = tv[r]; p.lp[dst] = lv[r]; p.anc[dst] = av[r];
-          }
-        }
-      }
-      if (lane == 0) {
-        int pe[MAX_K], ne[MAX_K];
-        for (int r = 0; r < k; ++r) {
-          const int par = s_parent[wave][r];
-          pe[r] = t == 0 ? 0 : p.has_eos[b * k + par];
-          ne[r] = t == 0 ? 1 : p.n_elem[b * k + par];
-        }
-        for (int r = 0; r < k; ++r) {
-          const long dst = base + (long)r * T;
-          p.tok[dst + t + 1] = (long long)s_word[wave][r];
-          p.lp[dst + t + 1] = s_lp[wave][r];
-          p.cumul[b * k + r] = s_cumul[wave][r];
-          p.n_elem[b * k + r] = ne[r] + (pe[r] ? 0 : 1);
-          p.has_eos[b * k + r] = (pe[r] || ((long long)s_word[wave][r] == p.eos)) ? 1 : 0;
-          p.row_valid[b * k + r] = pe[r] ? 0 : 1;
-          p.next_tok[b * k + r] = (long long)s_word[wave][r];
-          if (!pe[r]) alive_any = 1;
-        }
-      }
+    // cumulative score = re-summed per-token log-probs of the parent prefix + the new one (:213)
+    for (int r = 0; r < k; ++r) {
+      const long src = ((long)b * k + s_parent[r]) * T;
+      float cs = 0.f;
+      for (int j = 0; j <= t; ++j) cs += p.lp[src + j];
+      s_cumul[r] = cs + s_lp[r];
     }
-    __syncthreads();
   }
-  if (lane == 0) s_alive[wave] = alive_any;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int alive = s_alive[0] | s_alive[1] | s_alive[2] | s_alive[3];
-    if (!alive) *p.done = 1;
-    *p.pos = t + 1;
+  const long base = (long)b * k * T;
+  for (int j = lane; j <= t; j += 64) {
+    long long tv[MAX_K]; float lv[MAX_K]; int av[MAX_K];
+#pragma unroll
+    for (int r = 0; r < MAX_K; ++r) {
+      if (r < k) {
+        const long src = base + (long)s_parent[r] * T + j;
+        tv[r] = p.tok[src]; lv[r] = p.lp[src];
+        av[r] = j < t ? p.anc[src] : b * k + s_parent[r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < MAX_K; ++r) {
+      if (r < k) {
+        const long dst = base + (long)r * T + j;
+        p.tok[dst] = tv[r]; p.lp[dst] = lv[r]; p.anc[dst] = av[r];
+      }
+    }
+  }
+  if (lane == 0) {
+    int pe[MAX_K], ne[MAX_K];
+    for (int r = 0; r < k; ++r) {
+      const int par = s_parent[r];
+      pe[r] = t == 0 ? 0 : p.has_eos[b * k + par];
+      ne[r] = t == 0 ? 1 : p.n_elem[b * k + par];
+    }
+    for (int r = 0; r < k; ++r) {
+      const long dst = base + (long)r * T;
+      p.tok[dst + t + 1] = (long long)s_word[r];
+      p.lp[dst + t + 1] = s_lp[r];
+      p.cumul[b * k + r] = s_cumul[r];
+      p.n_elem[b * k + r] = ne[r] + (pe[r] ? 0 : 1);
+      p.has_eos[b * k + r] = (pe[r] || ((long long)s_word[r] == p.eos)) ? 1 : 0;
+      p.row_valid[b * k + r] = pe[r] ? 0 : 1;
+      p.next_tok[b * k + r] = (long long)s_word[r];
+      if (!pe[r]) alive_any = 1;
+    }
+    const int prev = atomicAdd(p.ctr, 1 + (alive_any << 16));
+    if ((prev & 0xffff) == p.n_img - 1) {            // every block has read *pos before arriving here
+      const int alive = (prev >> 16) + alive_any;
+      if (!alive) *p.done = 1;
+      *p.pos = t + 1;
+      *p.ctr = 0;
+    }
   }
 }
 
@@ -519,8 +531,10 @@ extern "C" int odic_dynexp_step(const float* lin, int64_t ldlin, const float* qe
   p.pos = pos; p.y_in = y_in; p.ldyi = ldy_in; p.y = y; p.ldy = ldy; p.scratch = scratch;
   p.N = N; p.T = T; p.d = d; p.E = E; p.eps = eps;
   hipStream_t s = (hipStream_t)stream;
-  const size_t shmem = (size_t)(2 * d + 2 * MAX_T + MAX_E + 2 * MAX_E + 8) * sizeof(float) + MAX_T * sizeof(int);
-  hipLaunchKernelGGL(dynexp_scores_kernel, dim3(N), dim3(256), shmem, s, p);
+  if (d % 64) return ODIC_EINVAL;
+  const size_t shmem = (size_t)(2 * d + 2 * MAX_T + MAX_E + 2 * MAX_E + 8 + MAX_T * E) * sizeof(float) +
+                       MAX_T * sizeof(int);
+  hipLaunchKernelGGL(dynexp_scores_kernel, dim3(N), dim3(512), shmem, s, p);
   dim3 grid(N, (d + 127) / 128);
   switch (E) {
     case 4: hipLaunchKernelGGL(dynexp_accum_kernel<4>, grid, dim3(128), 0, s, p); break;
@@ -551,8 +565,10 @@ extern "C" int odic_logsoftmax_topk(const float* logits, int64_t ldl, float* log
                                     int32_t* top_idx, int32_t N, int32_t V, int32_t k, void* stream) {
   if (!logits || !top_val || !top_idx) return ODIC_ENULL;
   if (N <= 0 || V <= 0 || k <= 0 || k > MAX_K || k > V) return ODIC_EINVAL;
-  hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, logp_out,
-                     (long)ldp, top_val, top_idx, V, k);
+  hipStream_t s = (hipStream_t)stream;
+  if (k <= 4) hipLaunchKernelGGL(logsoftmax_topk_kernel<4>, dim3(N), dim3(1024), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
+  else if (k <= 8) hipLaunchKernelGGL(logsoftmax_topk_kernel<8>, dim3(N), dim3(1024), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
+  else hipLaunchKernelGGL(logsoftmax_topk_kernel<16>, dim3(N), dim3(1024), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
   return odic_launch_status();
 }
 
@@ -561,15 +577,16 @@ extern "C" int odic_beam_step(const float* cand_val, const int32_t* cand_idx, co
   if (!cand_val || !cand_idx || !st) return ODIC_ENULL;
   if (n_img <= 0 || beams <= 0 || beams > MAX_K || T <= 1) return ODIC_EINVAL;
   if (!st->tokens || !st->logprobs || !st->anc || !st->cumul || !st->n_elem || !st->has_eos || !st->row_valid ||
-      !st->next_tok || !st->pos || !st->done)
+      !st->next_tok || !st->pos || !st->done || !st->ctr)
     return ODIC_ENULL;
+  if (n_img >= 65536) return ODIC_EINVAL;
   BeamParams p;
   p.cand_val = cand_val; p.cand_idx = cand_idx;
   p.tok = (long long*)st->tokens; p.lp = st->logprobs; p.anc = st->anc;
   p.cumul = st->cumul; p.n_elem = st->n_elem; p.has_eos = st->has_eos; p.row_valid = st->row_valid;
-  p.next_tok = (long long*)st->next_tok; p.pos = st->pos; p.done = st->done;
+  p.next_tok = (long long*)st->next_tok; p.pos = st->pos; p.done = st->done; p.ctr = st->ctr;
   p.n_img = n_img; p.k = beams; p.T = T; p.eos = eos_idx;
-  hipLaunchKernelGGL(beam_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(beam_step_kernel, dim3(n_img), dim3(64), 0, (hipStream_t)stream, p);
   return odic_launch_status();
 }
 

@@ -156,21 +156,29 @@ __global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int ksl
     am_ok[i] = m < p.M;
     arow[i] = A + (long)min(m, p.M - 1) * p.lda + 4 * fq;
   }
-  for (int k = k_begin; k < k_end; k += 16) {
-    float4 w4 = *(const float4*)(wrow + k);
-    if (!wn_ok) w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 a4[MT];
+  // All loads of a 64-deep K run are issued before the first MFMA (these kernels are latency-bound:
+  // the more requests in flight per wave the better); guards are applied on the loaded values.
+  constexpr int UN = (MT <= 4) ? 4 : 2;
+  for (int k = k_begin; k < k_end; k += 16 * UN) {
+    float4 w4[UN], a4[UN][MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      a4[i] = *(const float4*)(arow[i] + k);
-      if (!am_ok[i]) a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < UN; ++u) {
+      const int kk = min(k + 16 * u, p.K - 16);          // clamped address, masked below
+      w4[u] = *(const float4*)(wrow + kk);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a4[u][i] = *(const float4*)(arow[i] + kk);
     }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].x, w4.x, acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].y, w4.y, acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].z, w4.z, acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].w, w4.w, acc[i], 0, 0, 0);
+    for (int u = 0; u < UN; ++u) {
+      if (k + 16 * u >= k_end || !wn_ok) w4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (!am_ok[i]) a4[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][i].x, w4[u].x, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][i].y, w4[u].y, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][i].z, w4[u].z, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][i].w, w4[u].w, acc[i], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
@@ -199,8 +207,8 @@ __global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int ksl
 
 template <int MT>
 static void launch_skinny(const Params& p, int out_dtype, int batch, hipStream_t stream) {
-  // waves: aim at K-slices of ~128, at most 16 waves, LDS for the reduction <= 48 KiB
-  int nw = (p.K + 127) / 128;
+  // waves: aim at K-slices of ~64, at most 16 waves, LDS for the reduction <= 48 KiB
+  int nw = (p.K + 63) / 64;
   if (nw > 16) nw = 16;
   while (nw > 1 && nw * MT > 48) --nw;
   if (nw < 1) nw = 1;

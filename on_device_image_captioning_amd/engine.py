@@ -126,7 +126,7 @@ class DecodeState:
         self.dyn_scratch = f(N, 4 * T * E + T)
         self.row_valid = torch.ones(N, dtype=torch.int32, device=dv)
         self.next_tok = torch.zeros(N, dtype=torch.int64, device=dv)
-        self.pos, self.done = i32(1), i32(1)
+        self.pos, self.done, self.ctr = i32(1), i32(1), i32(1)
         self.tokens = torch.zeros(n_img, beams, T, dtype=torch.int64, device=dv)
         self.logprobs = f(n_img, beams, T)
         self.cumul, self.n_elem, self.has_eos = f(N), i32(N), i32(N)
@@ -134,7 +134,7 @@ class DecodeState:
         self.logits = f(N, g.vocab_size)
         self.beam_state = _hip.BeamState(*(t.data_ptr() for t in (
             self.tokens, self.logprobs, self.anc, self.cumul, self.n_elem, self.has_eos, self.row_valid,
-            self.next_tok, self.pos, self.done)))
+            self.next_tok, self.pos, self.done, self.ctr)))
 
 
 class CaptionerEngine:

@@ -24,6 +24,10 @@ from .captioning_model import CaptioningModel
 
 
 class CaptionPipeline:
+    """Two HIP streams: the encode graph of batch i+1 (compute-bound, fills the chip) runs while the
+    decode-step graph of batch i (latency-bound, a few dozen workgroups per kernel) is replayed.
+    `submit()` only enqueues; `collect()` returns the captions of the oldest outstanding batch."""
+
     def __init__(self, model: CaptioningModel, batch: int, beam_size: int, max_seq_len: int, sos_idx: int,
                  eos_idx: int, use_graphs: bool = True, done_poll: int = 0):
         """done_poll = 0: never look at the `done` flag (fixed work per batch — benchmark mode with
@@ -36,14 +40,28 @@ class CaptionPipeline:
         swin, cap = model._engines()
         self.swin, self.cap = swin, cap
         g, dv = cap.g, cap.device
+        self.device = dv
         self.img = torch.zeros(batch, g.swin_in_chans, g.swin_img_size, g.swin_img_size, dtype=torch.float32,
                                device=dv)
         S = g.stage_res(len(g.swin_depths) - 1) ** 2
         self.enc_len = torch.full((batch,), S, dtype=torch.int32, device=dv)
-        self.kv = torch.empty(batch, S, 2 * g.N_dec * g.d_model, dtype=torch.float32, device=dv)
+        kvshape = (batch, S, 2 * g.N_dec * g.d_model)
+        self.kv_stage = torch.empty(kvshape, dtype=torch.float32, device=dv)    # written by the encode graph
+        self.kv = torch.empty(kvshape, dtype=torch.float32, device=dv)          # read by the decode steps
         self.state = cap.new_state(batch, beam_size, self.T, self.kv, self.enc_len)
         self.order = torch.empty(batch, beam_size, dtype=torch.int32, device=dv)
         self.score = torch.empty(batch, beam_size, dtype=torch.float32, device=dv)
+        self.s_enc, self.s_dec = torch.cuda.Stream(device=dv), torch.cuda.Stream(device=dv)
+        self.ev_enc = torch.cuda.Event()
+        self.ev_kv_taken = torch.cuda.Event()
+        self.ev_kv_taken.record()
+        # results ring (device) + pinned host mirrors; depth 2 = one batch decoding, one being read
+        self.out_tok = [torch.zeros(batch, self.T, dtype=torch.int32, device=dv) for _ in range(2)]
+        self.out_len = [torch.zeros(batch, dtype=torch.int32, device=dv) for _ in range(2)]
+        self.host_tok = [torch.zeros(batch, self.T, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.host_len = [torch.zeros(batch, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._submitted = self._collected = 0
         self.g_enc: Optional[torch.cuda.CUDAGraph] = None
         self.g_step: Optional[torch.cuda.CUDAGraph] = None
         if use_graphs:
@@ -53,7 +71,7 @@ class CaptionPipeline:
     def _encode(self) -> None:
         feats = self.swin.forward(self.img)
         mem = self.cap.encode(feats, self.enc_len)
-        self.cap.project_kv(mem, out=self.kv)
+        self.cap.project_kv(mem, out=self.kv_stage)
 
     def _step(self) -> None:
         self.cap.beam_step(self.state, self.eos)
@@ -68,45 +86,63 @@ class CaptionPipeline:
         st.done.zero_()
 
     def _capture(self) -> None:
-        # warm-up on a side stream (allocator + lazy module loading), then capture
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(self.s_enc):                      # warm-up (allocator, lazy code load)
             self._encode()
+        with torch.cuda.stream(self.s_dec):
+            self.s_dec.wait_stream(self.s_enc)
+            self.kv.copy_(self.kv_stage)
             self._reset()
             self._step()
-        torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.g_enc = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_enc):
+        with torch.cuda.graph(self.g_enc, stream=self.s_enc):
             self._encode()
         self._reset()
         self.g_step = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_step):
+        with torch.cuda.graph(self.g_step, stream=self.s_dec):
             self._step()
         torch.cuda.synchronize()
 
     # -- public ---------------------------------------------------------------------------------
-    def enqueue(self, images: torch.Tensor) -> None:
-        """Queue one whole batch (no host synchronisation)."""
-        self.img.copy_(images, non_blocking=True)
-        if self.g_enc is not None:
-            self.g_enc.replay()
-        else:
-            self._encode()
-        self._reset()
-        for t in range(self.steps):
-            if self.g_step is not None:
-                self.g_step.replay()
+    def submit(self, images: torch.Tensor) -> None:
+        """Enqueue one batch on the two streams; never blocks the host (unless done_poll > 0)."""
+        if self._submitted - self._collected >= 2:
+            raise RuntimeError("at most two batches may be outstanding; call collect() first")
+        slot = self._submitted & 1
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(self.s_enc):
+            self.s_enc.wait_stream(cur)                          # `images` may have been produced there
+            self.s_enc.wait_event(self.ev_kv_taken)              # previous K/V hand-off finished
+            self.img.copy_(images, non_blocking=True)
+            if self.g_enc is not None:
+                self.g_enc.replay()
             else:
-                self._step()
-            if self.done_poll and t >= 1 and (t + 1) % self.done_poll == 0 and t + 1 < self.steps \
-                    and int(self.state.done.item()):
-                break
-        ops.beam_finalize(self.state.beam_state, self.order, self.score, self.B, self.k)
+                self._encode()
+            self.ev_enc.record()
+        with torch.cuda.stream(self.s_dec):
+            self.s_dec.wait_event(self.ev_enc)
+            self.kv.copy_(self.kv_stage)
+            self.ev_kv_taken.record()
+            self._reset()
+            for t in range(self.steps):
+                if self.g_step is not None:
+                    self.g_step.replay()
+                else:
+                    self._step()
+                if self.done_poll and t >= 1 and (t + 1) % self.done_poll == 0 and t + 1 < self.steps \
+                        and int(self.state.done.item()):
+                    break
+            ops.beam_finalize(self.state.beam_state, self.order, self.score, self.B, self.k)
+            toks, lens = self._best_tokens()
+            self.out_tok[slot].copy_(toks)
+            self.out_len[slot].copy_(lens)
+            self.host_tok[slot].copy_(self.out_tok[slot], non_blocking=True)
+            self.host_len[slot].copy_(self.out_len[slot], non_blocking=True)
+            self.ev_done[slot].record()
+        self._submitted += 1
 
-    def best_tokens(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Device tensors: best caption per image int64 [B, T] (EOS-padded) and its length int32 [B]."""
+    def _best_tokens(self) -> Tuple[torch.Tensor, torch.Tensor]:
         st = self.state
         best = self.order[:, 0].long()
         bidx = torch.arange(self.B, device=best.device)
@@ -115,11 +151,32 @@ class CaptionPipeline:
         pad = torch.arange(self.T, device=best.device)[None, :] >= lens[:, None]
         return toks.masked_fill(pad, self.eos), lens
 
-    def __call__(self, images: torch.Tensor) -> List[List[int]]:
-        self.enqueue(images)
-        toks, lens = self.best_tokens()
-        toks, lens = toks.cpu(), lens.cpu()
+    def outstanding(self) -> int:
+        return self._submitted - self._collected
+
+    def collect_device(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Device tensors (int32 [B,T] EOS-padded tokens, int32 [B] lengths) of the oldest outstanding
+        batch, ordered after its decode on the CURRENT stream (for a following collective)."""
+        if self._collected >= self._submitted:
+            raise RuntimeError("nothing outstanding")
+        slot = self._collected & 1
+        torch.cuda.current_stream().wait_event(self.ev_done[slot])
+        self._collected += 1
+        return self.out_tok[slot], self.out_len[slot]
+
+    def collect(self) -> List[List[int]]:
+        """Captions (token-id lists) of the oldest outstanding batch; blocks until it is decoded."""
+        if self._collected >= self._submitted:
+            raise RuntimeError("nothing outstanding")
+        slot = self._collected & 1
+        self.ev_done[slot].synchronize()
+        self._collected += 1
+        toks, lens = self.host_tok[slot], self.host_len[slot]
         return [toks[b, :int(lens[b])].tolist() for b in range(self.B)]
+
+    def __call__(self, images: torch.Tensor) -> List[List[int]]:
+        self.submit(images)
+        return self.collect()
 
 
 # =================================================================================================

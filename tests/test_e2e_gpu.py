@@ -268,3 +268,22 @@ def test_engine_is_hip_backed_and_cpu_model_refuses():
                             output_idx2word=list(range(g.vocab_size)), drop_args=make_drop_args(), rank="cpu")
     with pytest.raises(RuntimeError, match="no CPU"):
         m(enc_x=W.synth_images(1, g), enc_x_num_pads=[0], mode="beam_search", sos_idx=TSOS, eos_idx=TEOS)
+
+
+# ----------------------------------------------------------------------------------------- graph pipeline
+@pytest.mark.parametrize("variant,graphs,poll", [("eos", True, 0), ("eos", False, 4), ("xavier", True, 4)])
+def test_pipeline_matches_reference_best_caption(variant, graphs, poll):
+    """CaptionPipeline (two streams, hipGraph replay, deferred collection) returns the reference's
+    best beam-3 caption for every image, batch after batch."""
+    from on_device_image_captioning_amd.pipeline import CaptionPipeline
+    g = W.TINY
+    m = build_model("TINY", variant)
+    store = np.load(os.path.join(GOLDEN, f"tiny_{variant}.npz"))
+    want = [per[0] for per in unpad(store["beam3_T12.tokens"])]
+    img = W.synth_images(3, g).to(DEV)
+    pipe = CaptionPipeline(m, 3, 3, 12, TSOS, TEOS, use_graphs=graphs, done_poll=poll)
+    pipe.submit(img)
+    pipe.submit(img.flip(0).contiguous())
+    assert pipe.collect() == want
+    assert pipe.collect() == want[::-1]
+    assert pipe(img) == want
