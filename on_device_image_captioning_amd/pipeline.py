@@ -203,12 +203,12 @@ def gather_captions(tokens: torch.Tensor, lengths: torch.Tensor, n_items: int, g
     world = dist.get_world_size(group)
     t32 = tokens.to(torch.int32).contiguous()
     l32 = lengths.to(torch.int32).contiguous()
-    all_t = torch.empty((world,) + tuple(t32.shape), dtype=torch.int32, device=t32.device)
-    all_l = torch.empty((world,) + tuple(l32.shape), dtype=torch.int32, device=l32.device)
-    dist.all_gather_into_tensor(all_t, t32, group=group)
-    dist.all_gather_into_tensor(all_l, l32, group=group)
-    all_t = all_t.reshape(-1, t32.shape[-1]).cpu()
-    all_l = all_l.reshape(-1).cpu()
+    parts_t = [torch.empty_like(t32) for _ in range(world)]
+    parts_l = [torch.empty_like(l32) for _ in range(world)]
+    dist.all_gather(parts_t, t32, group=group)
+    dist.all_gather(parts_l, l32, group=group)
+    all_t = torch.cat(parts_t, 0).cpu()
+    all_l = torch.cat(parts_l, 0).cpu()
     return [all_t[i, :int(all_l[i])].tolist() for i in range(n_items)]
 
 
