@@ -85,6 +85,11 @@ void odic_gemm_bf16_force_config(int cfg);
 int odic_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, void* out,
                    int32_t M, int32_t C, float eps, int32_t out_dtype, void* stream);
 
+/* Row-strided fp32 → bf16 conversion (feeds fp32 residual streams / caller tensors to the bf16 MFMA
+ * GEMM).  x fp32 [M,C] (ldx) → out bf16 [M,C] (ldo); C, ldx, ldo multiples of 4. */
+int odic_cast_f32_to_bf16(const float* x, int64_t ldx, void* out, int64_t ldo, int32_t M, int32_t C,
+                          void* stream);
+
 /* PatchMerging gather + LayerNorm(4C)  (swin_transformer_mod.py:386-395):
  *   x fp32 [B, res*res, C] → out `out_dtype` [B, (res/2)², 4C]; channel blocks in the order
  *   (0,0),(1,0),(0,1),(1,1) of the 2x2 neighbourhood (row offset, col offset). */
@@ -119,17 +124,19 @@ int odic_window_attention(const void* qkv, const float* bias_table, void* out, i
  * odic_gemm; these kernels do the relu/mask/L1-normalise steps in between.
  *   z fp32 [B, nq, S]: Q·Kᵀ/sqrt(d).
  *   fw:  pos = relu(z)·valid, neg = relu(-z)·valid, each row divided by (rowsum + eps) over S
- *        (layers.py:56-61) → pos_fw, neg_fw fp32 [B, nq, S].  enc_len[b] = #valid keys (int32 [B]).
- *   bw:  relu(±zᵀ) [B, S, nq], each of the `ngroups` column groups L1-normalised separately
- *        (layers.py:67-79) and pre-divided by ngroups (:84-85) → pos_bw, neg_bw fp32 [B, S, nq].
+ *        (layers.py:56-61) → pos_fw, neg_fw `out_dtype` [B, nq, ld_fw].  enc_len[b] = #valid keys.
+ *   bw:  relu(±zᵀ), each of the `ngroups` column groups L1-normalised separately (layers.py:67-79)
+ *        and pre-divided by ngroups (:84-85) → pos_bw, neg_bw `out_dtype` [B, S, ld_bw].
+ *   ld_fw >= S and ld_bw >= nq: the padding columns are written as zeros, so the outputs can be the
+ *        K-padded operands of odic_gemm (bf16 needs K % 64 == 0).
  *   group_meta: device int32 [ngroups+1+nq] = exclusive prefix sums of the group sizes (last = nq)
  *        followed by the group index of every query row.
  *   colsum_ws: fp32 scratch [B*ngroups*2*S].
  * ------------------------------------------------------------------------------------------- */
 int odic_stcexp_normalize(const float* z, const int32_t* enc_len, const int32_t* group_meta,
-                          int32_t ngroups, float* pos_fw, float* neg_fw, float* pos_bw,
-                          float* neg_bw, float* colsum_ws, int32_t B, int32_t nq, int32_t S,
-                          float eps, void* stream);
+                          int32_t ngroups, void* pos_fw, void* neg_fw, int64_t ld_fw, void* pos_bw,
+                          void* neg_bw, int64_t ld_bw, float* colsum_ws, int32_t B, int32_t nq,
+                          int32_t S, float eps, int32_t out_dtype, void* stream);
 
 /* out = x + sigmoid(sel_pre)·a + (1-sigmoid(sel_pre))·b     (layers.py:99-100 + the residual add of
  * EncoderLayer :120); all fp32 [M, d] with row strides. */

@@ -80,7 +80,7 @@ class End_ExpansionNet_v2(CaptioningModel):
             dv = self._device()
             sd = self.state_dict()
             self._eng_cache = (_engine.SwinEngine(sd, self.geometry, dv, self.precision),
-                               _engine.CaptionerEngine(sd, self.geometry, dv))
+                               _engine.CaptionerEngine(sd, self.geometry, dv, self.precision))
         return self._eng_cache
 
     def _captioner_engine(self):
@@ -96,7 +96,7 @@ class End_ExpansionNet_v2(CaptioningModel):
             "End to End case have no padding"
         swin, cap = self._engines()
         img = enc_input.to(swin.device, torch.float32)
-        feats = swin.forward(img)
+        feats = swin.forward(img, out_dtype=cap.cdt)
         B, S, _ = feats.shape
         return cap.encode(feats, self._enc_lens(B, S, None))
 

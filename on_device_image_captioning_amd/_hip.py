@@ -46,10 +46,11 @@ _SIGNATURES = {
     "odic_gemm": (C.c_int, [C.POINTER(GemmArgs), _P]),
     "odic_gemm_bf16_force_config": (None, [C.c_int]),
     "odic_layernorm": (C.c_int, [_P, _I64, _P, _P, _P, _I32, _I32, _F, _I32, _P]),
+    "odic_cast_f32_to_bf16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P]),
     "odic_patch_merge_layernorm": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _F, _I32, _P]),
     "odic_patch_embed": (C.c_int, [_P] * 6 + [_I32] * 6 + [_F, _P]),
     "odic_window_attention": (C.c_int, [_P, _P, _P] + [_I32] * 6 + [_F, _I32, _P]),
-    "odic_stcexp_normalize": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P]),
+    "odic_stcexp_normalize": (C.c_int, [_P, _P, _P, _I32, _P, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _I32, _P]),
     "odic_selector_mix": (C.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _P]),
     "odic_dec_embed": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
     "odic_dynexp_step": (C.c_int, [_P, _I64, _P, _P] + [_P] * 7 + [_P, _P, _P, _P, _I64, _P, _I64, _P] + [_I32] * 4 + [_F, _P]),

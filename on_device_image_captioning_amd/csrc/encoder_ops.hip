@@ -13,10 +13,13 @@
 
 namespace {
 
+// fw: one wave per (b, q) row.  Output rows have leading dimension ld (>= S); columns S..ld-1 are
+// written as zeros so the buffers can feed a K-padded GEMM directly.
+template <typename OutT>
 __global__ __launch_bounds__(256) void stcexp_fw_kernel(const float* __restrict__ z,
                                                         const int* __restrict__ enc_len,
-                                                        float* __restrict__ pos_fw, float* __restrict__ neg_fw,
-                                                        int B, int nq, int S, float eps) {
+                                                        OutT* __restrict__ pos_fw, OutT* __restrict__ neg_fw,
+                                                        int B, int nq, int S, int ld, float eps) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long)B * nq) return;
@@ -31,39 +34,51 @@ __global__ __launch_bounds__(256) void stcexp_fw_kernel(const float* __restrict_
   }
   sp = wave_sum(sp); sn = wave_sum(sn);
   const float ip = 1.0f / (sp + eps), in_ = 1.0f / (sn + eps);
-  for (int s = lane; s < S; s += 64) {
-    const float v = s < len ? zr[s] : 0.f;
-    pos_fw[row * S + s] = fmaxf(v, 0.f) * ip;
-    neg_fw[row * S + s] = fmaxf(-v, 0.f) * in_;
+  for (int s = lane; s < ld; s += 64) {
+    const float v = (s < S && s < len) ? zr[s] : 0.f;
+    store_from_f32<OutT>(pos_fw + row * ld + s, fmaxf(v, 0.f) * ip);
+    store_from_f32<OutT>(neg_fw + row * ld + s, fmaxf(-v, 0.f) * in_);
   }
 }
 
-// grid (ceil(S/64), ngroups, B), block 64
-__global__ __launch_bounds__(64) void stcexp_colsum_kernel(const float* __restrict__ z,
-                                                           const int* __restrict__ group_start,
-                                                           float* __restrict__ colsum,   // [B, G, 2, S]
-                                                           int nq, int S) {
+// grid (ceil(S/64), ngroups, B), block (64, 8): 8 slices of the group's query range, LDS reduce
+__global__ __launch_bounds__(512) void stcexp_colsum_kernel(const float* __restrict__ z,
+                                                            const int* __restrict__ group_start,
+                                                            float* __restrict__ colsum,   // [B, G, 2, S]
+                                                            int nq, int S) {
+  __shared__ float rp[8][64];
+  __shared__ float rn[8][64];
   const int s = blockIdx.x * 64 + threadIdx.x;
   const int g = blockIdx.y, b = blockIdx.z, G = gridDim.y;
-  if (s >= S) return;
   const int q0 = group_start[g], q1 = group_start[g + 1];
   const float* zb = z + (long)b * nq * S;
   float sp = 0.f, sn = 0.f;
-  for (int q = q0; q < q1; ++q) {
-    const float v = zb[(long)q * S + s];
-    sp += fmaxf(v, 0.f);
-    sn += fmaxf(-v, 0.f);
+  if (s < S) {
+    for (int q = q0 + threadIdx.y; q < q1; q += 8) {
+      const float v = zb[(long)q * S + s];
+      sp += fmaxf(v, 0.f);
+      sn += fmaxf(-v, 0.f);
+    }
   }
-  colsum[(((long)b * G + g) * 2 + 0) * S + s] = sp;
-  colsum[(((long)b * G + g) * 2 + 1) * S + s] = sn;
+  rp[threadIdx.y][threadIdx.x] = sp;
+  rn[threadIdx.y][threadIdx.x] = sn;
+  __syncthreads();
+  if (threadIdx.y == 0 && s < S) {
+    float tp = 0.f, tn = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { tp += rp[i][threadIdx.x]; tn += rn[i][threadIdx.x]; }
+    colsum[(((long)b * G + g) * 2 + 0) * S + s] = tp;
+    colsum[(((long)b * G + g) * 2 + 1) * S + s] = tn;
+  }
 }
 
-// grid (ceil(S/32), ceil(nq/32), B), block (32, 8)
+// grid (ceil(S/32), ceil(ld/32), B), block (32, 8); output [B, S, ld] with zeroed columns nq..ld-1
+template <typename OutT>
 __global__ __launch_bounds__(256) void stcexp_bw_kernel(const float* __restrict__ z,
                                                         const float* __restrict__ colsum,
                                                         const int* __restrict__ group_of_q,
-                                                        float* __restrict__ pos_bw, float* __restrict__ neg_bw,
-                                                        int nq, int S, int G, float eps, float inv_g) {
+                                                        OutT* __restrict__ pos_bw, OutT* __restrict__ neg_bw,
+                                                        int nq, int S, int ld, int G, float eps, float inv_g) {
   __shared__ float tp[32][33];
   __shared__ float tn[32][33];
   const int b = blockIdx.z;
@@ -86,9 +101,9 @@ __global__ __launch_bounds__(256) void stcexp_bw_kernel(const float* __restrict_
   __syncthreads();
   for (int i = threadIdx.y; i < 32; i += 8) {
     const int s = s0 + i, q = q0 + threadIdx.x;
-    if (s < S && q < nq) {
-      pos_bw[((long)b * S + s) * nq + q] = tp[threadIdx.x][i];
-      neg_bw[((long)b * S + s) * nq + q] = tn[threadIdx.x][i];
+    if (s < S && q < ld) {
+      store_from_f32<OutT>(pos_bw + ((long)b * S + s) * ld + q, tp[threadIdx.x][i]);
+      store_from_f32<OutT>(neg_bw + ((long)b * S + s) * ld + q, tn[threadIdx.x][i]);
     }
   }
 }
@@ -107,25 +122,35 @@ __global__ __launch_bounds__(256) void selector_mix_kernel(const float* __restri
 
 }  // namespace
 
-// workspace layout for odic_stcexp_normalize: the caller passes `group_sizes` as a DEVICE int32 array
-// of length 2*ngroups+1+nq:  [0..ngroups]  exclusive prefix sums (group starts, last = nq),
-//                            [ngroups+1 .. ngroups+nq] group index of every query row,
-// and `colsum_ws` (fp32, B*ngroups*2*S) folded behind neg_bw by the Python side — see ops.py.
-extern "C" int odic_stcexp_normalize(const float* z, const int32_t* enc_len, const int32_t* group_meta,
-                                     int32_t ngroups, float* pos_fw, float* neg_fw, float* pos_bw,
-                                     float* neg_bw, float* colsum_ws, int32_t B, int32_t nq, int32_t S,
-                                     float eps, void* stream) {
-  if (!z || !enc_len || !group_meta || !pos_fw || !neg_fw || !pos_bw || !neg_bw || !colsum_ws) return ODIC_ENULL;
-  if (B <= 0 || nq <= 0 || S <= 0 || ngroups <= 0 || B > 65535) return ODIC_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
+template <typename OutT>
+static int stcexp_launch(const float* z, const int32_t* enc_len, const int32_t* group_meta, int32_t ngroups,
+                         void* pos_fw, void* neg_fw, int64_t ld_fw, void* pos_bw, void* neg_bw, int64_t ld_bw,
+                         float* colsum_ws, int32_t B, int32_t nq, int32_t S, float eps, hipStream_t s) {
   const long rows = (long)B * nq;
-  hipLaunchKernelGGL(stcexp_fw_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, enc_len, pos_fw,
-                     neg_fw, B, nq, S, eps);
-  hipLaunchKernelGGL(stcexp_colsum_kernel, dim3((S + 63) / 64, ngroups, B), dim3(64), 0, s, z, group_meta,
+  hipLaunchKernelGGL(stcexp_fw_kernel<OutT>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, enc_len,
+                     (OutT*)pos_fw, (OutT*)neg_fw, B, nq, S, (int)ld_fw, eps);
+  hipLaunchKernelGGL(stcexp_colsum_kernel, dim3((S + 63) / 64, ngroups, B), dim3(64, 8), 0, s, z, group_meta,
                      colsum_ws, nq, S);
-  hipLaunchKernelGGL(stcexp_bw_kernel, dim3((S + 31) / 32, (nq + 31) / 32, B), dim3(32, 8), 0, s, z, colsum_ws,
-                     group_meta + ngroups + 1, pos_bw, neg_bw, nq, S, ngroups, eps, 1.0f / (float)ngroups);
+  hipLaunchKernelGGL(stcexp_bw_kernel<OutT>, dim3((S + 31) / 32, (unsigned)((ld_bw + 31) / 32), B), dim3(32, 8), 0, s,
+                     z, colsum_ws, group_meta + ngroups + 1, (OutT*)pos_bw, (OutT*)neg_bw, nq, S, (int)ld_bw, ngroups,
+                     eps, 1.0f / (float)ngroups);
   return odic_launch_status();
+}
+
+extern "C" int odic_stcexp_normalize(const float* z, const int32_t* enc_len, const int32_t* group_meta,
+                                     int32_t ngroups, void* pos_fw, void* neg_fw, int64_t ld_fw, void* pos_bw,
+                                     void* neg_bw, int64_t ld_bw, float* colsum_ws, int32_t B, int32_t nq, int32_t S,
+                                     float eps, int32_t out_dtype, void* stream) {
+  if (!z || !enc_len || !group_meta || !pos_fw || !neg_fw || !pos_bw || !neg_bw || !colsum_ws) return ODIC_ENULL;
+  if (B <= 0 || nq <= 0 || S <= 0 || ngroups <= 0 || B > 65535 || ld_fw < S || ld_bw < nq) return ODIC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (out_dtype == ODIC_F32)
+    return stcexp_launch<float>(z, enc_len, group_meta, ngroups, pos_fw, neg_fw, ld_fw, pos_bw, neg_bw, ld_bw,
+                                colsum_ws, B, nq, S, eps, s);
+  if (out_dtype == ODIC_BF16)
+    return stcexp_launch<bf16_raw>(z, enc_len, group_meta, ngroups, pos_fw, neg_fw, ld_fw, pos_bw, neg_bw, ld_bw,
+                                   colsum_ws, B, nq, S, eps, s);
+  return ODIC_EINVAL;
 }
 
 extern "C" int odic_selector_mix(const float* x, int64_t ldx, const float* sel_pre, int64_t lds_, const float* a,

@@ -178,7 +178,29 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
   }
 }
 
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, long ldx,
+                                                        bf16_raw* __restrict__ out, long ldo, int M, int C4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)M * C4) return;
+  const int r = i / C4, c = (i - (long)r * C4) * 4;
+  const float4 v = *(const float4*)(x + r * ldx + c);
+  ushort4 pk;
+  pk.x = f32_to_bf16(v.x); pk.y = f32_to_bf16(v.y); pk.z = f32_to_bf16(v.z); pk.w = f32_to_bf16(v.w);
+  *(ushort4*)(out + r * ldo + c) = pk;
+}
+
 }  // namespace
+
+extern "C" int odic_cast_f32_to_bf16(const float* x, int64_t ldx, void* out, int64_t ldo, int32_t M, int32_t C,
+                                     void* stream) {
+  if (!x || !out) return ODIC_ENULL;
+  if (M <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldo & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 7))
+    return ODIC_EINVAL;
+  const long n = (long)M * (C / 4);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)ldx, (bf16_raw*)out, (long)ldo, M, C / 4);
+  return odic_launch_status();
+}
 
 extern "C" int odic_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, void* out,
                               int32_t M, int32_t C, float eps, int32_t out_dtype, void* stream) {

@@ -71,8 +71,8 @@ class SwinEngine:
             self.stages.append((blocks, down))
         self.fn_w, self.fn_b = f32(f"{P}.norm.weight"), f32(f"{P}.norm.bias")
 
-    def forward(self, img: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
-        """img fp32 [B,3,H,W] on the engine's device → features fp32 [B, res_last², C_last]."""
+    def forward(self, img: torch.Tensor, taps: Optional[dict] = None, out_dtype=torch.float32) -> torch.Tensor:
+        """img fp32 [B,3,H,W] on the engine's device → features [B, res_last², C_last] (`out_dtype`)."""
         g, cdt = self.g, self.cdt
         if img.dtype != torch.float32 or not img.is_cuda:
             raise RuntimeError("SwinEngine.forward wants an fp32 CUDA image batch")
@@ -100,7 +100,7 @@ class SwinEngine:
                 if taps is not None:
                     taps[f"merge{s}"] = x.view(B, (res // 2) ** 2, 2 * C_).clone()
         res = g.stage_res(len(g.swin_depths) - 1)
-        out = ops.layernorm(x, self.fn_w, self.fn_b, out_dtype=torch.float32)
+        out = ops.layernorm(x, self.fn_w, self.fn_b, out_dtype=out_dtype)
         return out.view(B, res * res, -1)
 
 
@@ -138,12 +138,17 @@ class DecodeState:
 
 
 class CaptionerEngine:
-    def __init__(self, sd: SD, g: Geometry, device):
-        self.g, self.device = g, device
+    """precision 'fp32': everything exact fp32.  'bf16': the ENCODER's products run on the bf16 MFMA
+    GEMM (fp32 accumulation, fp32 residual streams, fp32 normalisations); the decoder stays fp32."""
+
+    def __init__(self, sd: SD, g: Geometry, device, precision: str = "fp32"):
+        self.g, self.device, self.precision = g, device, precision
+        self.cdt = _CDT[precision]
         d = g.d_model
         f32 = lambda k: _dev(sd[k], device, torch.float32)          # noqa: E731
         cat = lambda ks: torch.cat([f32(k) for k in ks], 0).contiguous()   # noqa: E731
-        self.in_w, self.in_b = f32("input_linear.weight"), f32("input_linear.bias")
+        cw = lambda t: t.to(self.cdt).contiguous()                  # noqa: E731  (encoder GEMM operand dtype)
+        self.in_w, self.in_b = cw(f32("input_linear.weight")), f32("input_linear.bias")
         self.enc = []
         for i in range(g.N_enc):
             p = f"encoders.{i}"
@@ -151,15 +156,15 @@ class CaptionerEngine:
             self.enc.append(dict(
                 n1w=f32(p + ".norm_1.weight"), n1b=f32(p + ".norm_1.bias"),
                 n2w=f32(p + ".norm_2.weight"), n2b=f32(p + ".norm_2.bias"),
-                q=f32(s + ".query_exp_vectors.weight"),
-                bvT=f32(s + ".bias_exp_vectors.weight").t().contiguous(),              # [d, nq]
-                ks_w=cat([s + ".key_embed.weight", s + ".selector_embed.weight"]),     # [2d, d]
-                ks_b=cat([s + ".key_embed.bias", s + ".selector_embed.bias"]),
-                ab_w=cat([s + ".class_a_embed.weight", s + ".class_b_embed.weight"]),  # [2d, d]
+                q=cw(f32(s + ".query_exp_vectors.weight")),
+                bvT=f32(s + ".bias_exp_vectors.weight").t().contiguous(),              # [d, nq] fp32
+                key_w=cw(f32(s + ".key_embed.weight")), key_b=f32(s + ".key_embed.bias"),
+                sel_w=cw(f32(s + ".selector_embed.weight")), sel_b=f32(s + ".selector_embed.bias"),
+                ab_w=cw(cat([s + ".class_a_embed.weight", s + ".class_b_embed.weight"])),  # [2d, d]
                 ab_b=cat([s + ".class_a_embed.bias", s + ".class_b_embed.bias"]),
-                f1w=f32(p + ".ff.linear_1.weight"), f1b=f32(p + ".ff.linear_1.bias"),
-                f2w=f32(p + ".ff.linear_2.weight"), f2b=f32(p + ".ff.linear_2.bias")))
-        self.er_w, self.er_b = f32("enc_reduce_group.weight"), f32("enc_reduce_group.bias")
+                f1w=cw(f32(p + ".ff.linear_1.weight")), f1b=f32(p + ".ff.linear_1.bias"),
+                f2w=cw(f32(p + ".ff.linear_2.weight")), f2b=f32(p + ".ff.linear_2.bias")))
+        self.er_w, self.er_b = cw(f32("enc_reduce_group.weight")), f32("enc_reduce_group.bias")
         self.ern_w, self.ern_b = f32("enc_reduce_norm.weight"), f32("enc_reduce_norm.bias")
         self.group_meta = ops.stcexp_group_meta(g.num_exp_enc_list, device)
         self.dec = []
@@ -180,60 +185,80 @@ class CaptionerEngine:
                 f2w=f32(p + ".ff.linear_2.weight"), f2b=f32(p + ".ff.linear_2.bias")))
             kvw += [p + ".mha.Wk.weight", p + ".mha.Wv.weight"]
             kvb += [p + ".mha.Wk.bias", p + ".mha.Wv.bias"]
-        self.kv_w, self.kv_b = cat(kvw), cat(kvb)                   # [2·N_dec·d, d]
+        self.kv_w32, self.kv_b = cat(kvw), cat(kvb)                 # [2·N_dec·d, d]
+        self.kv_w = cw(self.kv_w32)
         self.dr_w, self.dr_b = f32("dec_reduce_group.weight"), f32("dec_reduce_group.bias")
         self.drn_w, self.drn_b = f32("dec_reduce_norm.weight"), f32("dec_reduce_norm.bias")
         self.voc_w, self.voc_b = f32("vocab_linear.weight"), f32("vocab_linear.bias")
         self.embed, self.pos_table = f32("out_embedder.embed.weight"), f32("pos_encoder.weight")
 
     # ------------------------------------------------------------------------------------------
-    def encode(self, feats: torch.Tensor, enc_len: torch.Tensor) -> torch.Tensor:
-        """feats fp32 [B,S,F] → encoder output fp32 [B,S,d]  (forward_enc after the backbone:
-        End_ExpansionNet_v2.py:82-101 / ExpansionNet_v2.py:52-70).  enc_len int32 [B] on device."""
-        g, dv = self.g, self.device
+    def _as_operand(self, x: torch.Tensor, M: int, C_: int, ldx: int) -> torch.Tensor:
+        """fp32 activations → the encoder GEMM operand dtype (identity view in fp32 mode)."""
+        if x.dtype == self.cdt:
+            return x
+        if self.cdt == torch.bfloat16 and x.dtype == torch.float32:
+            return ops.cast_bf16(x, M=M, C_=C_, ldx=ldx)
+        raise RuntimeError(f"cannot feed {x.dtype} to a {self.cdt} encoder")
+
+    def encode(self, feats: torch.Tensor, enc_len: torch.Tensor, want_bf16_mem: bool = False):
+        """feats [B,S,F] (fp32, or bf16 in bf16 mode) → encoder output fp32 [B,S,d]  (forward_enc after
+        the backbone: End_ExpansionNet_v2.py:82-101 / ExpansionNet_v2.py:52-70).  enc_len int32 [B]."""
+        g, dv, cdt = self.g, self.device, self.cdt
         B, S, F = feats.shape
         d, L, nq, M = g.d_model, g.N_enc, sum(g.num_exp_enc_list), B * S
+        pad = 64 if cdt == torch.bfloat16 else 1                   # the bf16 GEMM needs K % 64 == 0
+        Sp, nqp = -(-S // pad) * pad, -(-nq // pad) * pad
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dv)      # noqa: E731
-        x0 = ops.gemm(feats.reshape(M, F).contiguous(), self.in_w, self.in_b)            # [M,d]
+        zc = lambda *s: torch.zeros(*s, dtype=cdt, device=dv)               # noqa: E731  (K padding must be finite)
+        feats2 = feats.reshape(M, F)
+        if not feats2.is_contiguous():
+            feats2 = feats2.contiguous()
+        x0 = ops.gemm(self._as_operand(feats2, M, F, F), self.in_w, self.in_b, out_dtype=torch.float32)   # [M,d]
         xcat = f(M, L * d)
-        z, pf, nf = f(B, nq, S), f(B, nq, S), f(B, nq, S)
-        pb, nb = f(B, S, nq), f(B, S, nq)
+        z = f(B, nq, S)
+        pf, nf = zc(B, nq, Sp), zc(B, nq, Sp)
+        pb, nb = zc(B, S, nqp), zc(B, S, nqp)
         colsum = f(B * len(g.num_exp_enc_list) * 2 * S)
-        AT, BT = f(B, d, nq), f(B, d, nq)
+        AT, BT = zc(B, d, nqp), zc(B, d, nqp)
         A2, B2 = f(B, S, d), f(B, S, d)
-        vabT = f(B, 2 * d, S)
+        vabT = zc(B, 2 * d, Sp)
+        key = torch.empty(M, d, dtype=cdt, device=dv)
         ld = L * d
         for i, w in enumerate(self.enc):
             xin, ldin = (x0, d) if i == 0 else (xcat[:, (i - 1) * d:], ld)
             xo = xcat[:, i * d:]
-            x2 = ops.layernorm(xin, w["n1w"], w["n1b"], M=M, C_=d, ldx=ldin)
-            lin = ops.gemm(x2, w["ks_w"], w["ks_b"])                                         # key | sel
+            x2 = ops.layernorm(xin, w["n1w"], w["n1b"], M=M, C_=d, ldx=ldin, out_dtype=cdt)
+            ops.gemm(x2, w["key_w"], w["key_b"], out=key)
+            sel = ops.gemm(x2, w["sel_w"], w["sel_b"], out_dtype=torch.float32)
             # (class_a | class_b) projections, produced transposed: [B, 2d, S] = W·x2ᵀ + b(row)
-            ops.gemm(w["ab_w"], x2, w["ab_b"], out=vabT, bias_axis=1, M=2 * d, N=S, K=d, lda=d, ldw=d, ldc=S,
-                     batch=B, strideA=0, strideW=S * d, strideC=2 * d * S)
+            ops.gemm(w["ab_w"], x2, w["ab_b"], out=vabT, bias_axis=1, M=2 * d, N=S, K=d, lda=d, ldw=d, ldc=Sp,
+                     batch=B, strideA=0, strideW=S * d, strideC=2 * d * Sp)
             # z = Q·Kᵀ/sqrt(d)
-            ops.gemm(w["q"], lin, out=z, alpha=1.0 / math.sqrt(d), M=nq, N=S, K=d, lda=d, ldw=2 * d, ldc=S,
-                     batch=B, strideA=0, strideW=S * 2 * d, strideC=nq * S)
+            ops.gemm(w["q"], key, out=z, alpha=1.0 / math.sqrt(d), M=nq, N=S, K=d, lda=d, ldw=d, ldc=S,
+                     batch=B, strideA=0, strideW=S * d, strideC=nq * S)
             ops.stcexp_normalize(z, enc_len, self.group_meta, len(g.num_exp_enc_list), pf, nf, pb, nb, colsum)
             # class_aᵀ [d,nq] = Vaᵀ·pos_fwᵀ + Bvᵀ    (layers.py:63-64, transposed)
-            ops.gemm(vabT, pf, residual=w["bvT"], out=AT, M=d, N=nq, K=S, lda=S, ldw=S, ldr=nq, ldc=nq, batch=B,
-                     strideA=2 * d * S, strideW=nq * S, strideR=0, strideC=d * nq)
-            ops.gemm(vabT[:, d:], nf, residual=w["bvT"], out=BT, M=d, N=nq, K=S, lda=S, ldw=S, ldr=nq, ldc=nq,
-                     batch=B, strideA=2 * d * S, strideW=nq * S, strideR=0, strideC=d * nq)
+            ops.gemm(vabT, pf, residual=w["bvT"], out=AT, M=d, N=nq, K=Sp, lda=Sp, ldw=Sp, ldr=nq, ldc=nqp, batch=B,
+                     strideA=2 * d * Sp, strideW=nq * Sp, strideR=0, strideC=d * nqp)
+            ops.gemm(vabT[:, d:], nf, residual=w["bvT"], out=BT, M=d, N=nq, K=Sp, lda=Sp, ldw=Sp, ldr=nq, ldc=nqp,
+                     batch=B, strideA=2 * d * Sp, strideW=nq * Sp, strideR=0, strideC=d * nqp)
             # backward: [S,nq]·[nq,d]
-            ops.gemm(pb, AT, out=A2, M=S, N=d, K=nq, lda=nq, ldw=nq, ldc=d, batch=B, strideA=S * nq,
-                     strideW=d * nq, strideC=S * d)
-            ops.gemm(nb, BT, out=B2, M=S, N=d, K=nq, lda=nq, ldw=nq, ldc=d, batch=B, strideA=S * nq,
-                     strideW=d * nq, strideC=S * d)
-            ops.selector_mix(xin, ldin, lin[:, d:], 2 * d, A2, d, B2, d, xo, ld, M, d)
-            x2 = ops.layernorm(xo, w["n2w"], w["n2b"], M=M, C_=d, ldx=ld)
+            ops.gemm(pb, AT, out=A2, M=S, N=d, K=nqp, lda=nqp, ldw=nqp, ldc=d, batch=B, strideA=S * nqp,
+                     strideW=d * nqp, strideC=S * d)
+            ops.gemm(nb, BT, out=B2, M=S, N=d, K=nqp, lda=nqp, ldw=nqp, ldc=d, batch=B, strideA=S * nqp,
+                     strideW=d * nqp, strideC=S * d)
+            ops.selector_mix(xin, ldin, sel, d, A2, d, B2, d, xo, ld, M, d)
+            x2 = ops.layernorm(xo, w["n2w"], w["n2b"], M=M, C_=d, ldx=ld, out_dtype=cdt)
             h = ops.gemm(x2, w["f1w"], w["f1b"], act=ops.ACT_RELU)
             ops.gemm(h, w["f2w"], w["f2b"], residual=xo, out=xo, M=M, N=d, K=g.ff, lda=g.ff, ldw=g.ff, ldr=ld,
                      ldc=ld)
-        pre = ops.gemm(xcat, self.er_w, self.er_b, residual=xcat[:, (L - 1) * d:], M=M, N=d, K=L * d, lda=ld,
-                       ldw=ld, ldr=ld, ldc=d, out=f(M, d))
-        mem = ops.layernorm(pre, self.ern_w, self.ern_b)
-        return mem.view(B, S, d)
+        pre = ops.gemm(self._as_operand(xcat, M, ld, ld), self.er_w, self.er_b, residual=xcat[:, (L - 1) * d:], M=M,
+                       N=d, K=ld, lda=ld, ldw=ld, ldr=ld, ldc=d, out=f(M, d))
+        mem = ops.layernorm(pre, self.ern_w, self.ern_b).view(B, S, d)
+        if want_bf16_mem and cdt == torch.bfloat16:
+            return mem, ops.layernorm(pre, self.ern_w, self.ern_b, out_dtype=cdt).view(B, S, d)
+        return mem
 
     def project_kv(self, mem: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Cross-attention K/V of every decoder layer, once per image (the reference recomputes them
@@ -242,8 +267,13 @@ class CaptionerEngine:
         n = self.kv_w.shape[0]
         if out is None:
             out = torch.empty(B, S, n, dtype=torch.float32, device=self.device)
-        ops.gemm(mem.reshape(B * S, d).contiguous(), self.kv_w, self.kv_b, out=out, M=B * S, N=n, K=d, lda=d, ldw=d,
-                 ldc=n)
+        a = mem.reshape(B * S, d)
+        if not a.is_contiguous():
+            a = a.contiguous()
+        w = self.kv_w if a.dtype == self.kv_w.dtype else self.kv_w32
+        if a.dtype != w.dtype:
+            a = a.to(w.dtype)
+        ops.gemm(a, w, self.kv_b, out=out, M=B * S, N=n, K=d, lda=d, ldw=d, ldc=n)
         return out
 
     # ------------------------------------------------------------------------------------------

@@ -146,6 +146,20 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, eps: 
     return out
 
 
+def cast_bf16(x: torch.Tensor, *, M: Optional[int] = None, C_: Optional[int] = None, ldx: Optional[int] = None
+              ) -> torch.Tensor:
+    """fp32 [M,C] (row stride ldx) → contiguous bf16 [M,C]."""
+    _need_cuda(x)
+    if M is None:
+        C_ = x.shape[-1]
+        M = x.numel() // C_
+        ldx = C_
+    out = torch.empty((M, C_), dtype=torch.bfloat16, device=x.device)
+    with _timed("cast_bf16", 0.0, M * C_ * 6.0):
+        _hip.check(_hip.load().odic_cast_f32_to_bf16(_p(x), ldx, _p(out), C_, M, C_, _stream()), "odic_cast_f32_to_bf16")
+    return out
+
+
 def patch_merge_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, res: int, Cin: int,
                           *, eps: float = 1e-5, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
     _need_cuda(x, gamma, beta)
@@ -203,12 +217,14 @@ def stcexp_group_meta(groups: Sequence[int], device) -> torch.Tensor:
 def stcexp_normalize(z: torch.Tensor, enc_len: torch.Tensor, group_meta: torch.Tensor, ngroups: int,
                      pos_fw: torch.Tensor, neg_fw: torch.Tensor, pos_bw: torch.Tensor, neg_bw: torch.Tensor,
                      colsum_ws: torch.Tensor, *, eps: float = 1e-9) -> None:
+    """Outputs may be fp32 or bf16 and wider than (S / nq): padding columns are zero-filled."""
     _need_cuda(z, enc_len, group_meta, pos_fw, neg_fw, pos_bw, neg_bw, colsum_ws)
     B, nq, S = z.shape
     with _timed("stcexp_normalize", 0.0, 0.0):
         _hip.check(_hip.load().odic_stcexp_normalize(_p(z), _p(enc_len), _p(group_meta), ngroups, _p(pos_fw),
-                                                     _p(neg_fw), _p(pos_bw), _p(neg_bw), _p(colsum_ws), B, nq, S, eps,
-                                                     _stream()), "odic_stcexp_normalize")
+                                                     _p(neg_fw), pos_fw.shape[-1], _p(pos_bw), _p(neg_bw),
+                                                     pos_bw.shape[-1], _p(colsum_ws), B, nq, S, eps,
+                                                     dtype_code(pos_fw.dtype), _stream()), "odic_stcexp_normalize")
 
 
 def selector_mix(x, ldx, sel_pre, lds, a, lda, b, ldb, out, ldo, M, d) -> None:

@@ -69,9 +69,12 @@ class CaptionPipeline:
 
     # -- the two captured regions ---------------------------------------------------------------
     def _encode(self) -> None:
-        feats = self.swin.forward(self.img)
-        mem = self.cap.encode(feats, self.enc_len)
-        self.cap.project_kv(mem, out=self.kv_stage)
+        feats = self.swin.forward(self.img, out_dtype=self.cap.cdt)
+        if self.cap.cdt == torch.bfloat16:
+            _, mem16 = self.cap.encode(feats, self.enc_len, want_bf16_mem=True)
+            self.cap.project_kv(mem16, out=self.kv_stage)
+        else:
+            self.cap.project_kv(self.cap.encode(feats, self.enc_len), out=self.kv_stage)
 
     def _step(self) -> None:
         self.cap.beam_step(self.state, self.eos)

@@ -190,6 +190,14 @@ def test_stcexp_normalize_and_mix(ops):
     ops.stcexp_normalize(dev(z), dev(lens), ops.stcexp_group_meta(groups, d), len(groups), *o, ws)
     assert_close(o[0], pf, 2e-5, "pos_fw"); assert_close(o[1], nf, 2e-5, "neg_fw")
     assert_close(o[2], pb / len(groups), 2e-5, "pos_bw"); assert_close(o[3], nb / len(groups), 2e-5, "neg_bw")
+    # bf16 outputs with zero-filled K padding (operands of the bf16 GEMM)
+    ob = [torch.full((B, nq, 64), 7.0, device=d, dtype=torch.bfloat16) for _ in range(2)] + \
+         [torch.full((B, S, 64), 7.0, device=d, dtype=torch.bfloat16) for _ in range(2)]
+    ops.stcexp_normalize(dev(z), dev(lens), ops.stcexp_group_meta(groups, d), len(groups), *ob, ws)
+    assert_close(ob[0][:, :, :S], pf, 5e-3, "pos_fw bf16"); assert_close(ob[3][:, :, :nq], nb / len(groups), 5e-3, "neg_bw bf16")
+    assert float(ob[0][:, :, S:].abs().max()) == 0.0 and float(ob[2][:, :, nq:].abs().max()) == 0.0
+    xc = rnd(37, 96, seed=8)
+    assert torch.equal(ops.cast_bf16(dev(xc)).cpu(), xc.bfloat16())
     M, dm = 50, 128
     x, s, a, b = (rnd(M, dm, seed=i) for i in range(4))
     out = torch.empty(M, dm, device=d)
