@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=6)
+    ap.add_argument("--decode-lanes", type=int, default=2)
     return ap.parse_args()
 
 
@@ -69,7 +70,7 @@ def roofline_pass(pipe, images):
     """One extra eager pass of the same workload with per-launch HIP events."""
     from on_device_image_captioning_amd import ops
     g_enc, g_step = pipe.g_enc, pipe.g_step
-    pipe.g_enc = pipe.g_step = None           # eager launches so that events bracket single kernels
+    pipe.g_enc, pipe.g_step = None, [None] * pipe.D           # eager launches: events bracket single kernels
     try:
         pipe(images)                           # warm
         torch.cuda.synchronize()
@@ -149,7 +150,8 @@ def main():
     from on_device_image_captioning_amd.pipeline import CaptionPipeline, gather_captions
     torch.set_grad_enabled(False)
     model, sd, g = build_model(device, a.precision)
-    pipe = CaptionPipeline(model, a.batch, a.beam, a.max_len, SOS, EOS, use_graphs=not a.no_graphs)
+    pipe = CaptionPipeline(model, a.batch, a.beam, a.max_len, SOS, EOS, use_graphs=not a.no_graphs,
+                           decode_lanes=a.decode_lanes)
     images = W.synth_images(a.batch, g, seed=42 + rank).to(device)         # resident in HBM
 
     def finish_one():
@@ -165,7 +167,7 @@ def main():
         caps = None
         for _ in range(n):
             pipe.submit(images)
-            if pipe.outstanding() == 2:
+            if pipe.full():
                 caps = finish_one()
         while pipe.outstanding():
             caps = finish_one()
@@ -199,7 +201,7 @@ def main():
                        "decoder_steps": pipe.steps, "weights": "synthetic xavier (Philox, seed 0)",
                        "backbone_precision": a.precision, "captioner_precision": "fp32",
                        "hip_graphs": not a.no_graphs, "parallelism": f"image-shard x{world}",
-                       "caption_len_check": min(len(c) for c in caps), "overlap": "encode(i+1) || decode(i) on two HIP streams"},
+                       "caption_len_check": min(len(c) for c in caps), "overlap": "encode(i+1) || decode(i) || decode(i-1) on three HIP streams"},
         }
         if not a.no_roofline:
             fam = roofline_pass(pipe, images)

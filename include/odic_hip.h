@@ -40,7 +40,7 @@ extern "C" {
 #define ODIC_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ODIC_ABI_VERSION 1
+#define ODIC_ABI_VERSION 2
 int odic_abi_version(void);
 
 /* Human-readable build string ("gfx950 hipcc ..."), static storage. */
@@ -69,11 +69,12 @@ typedef struct odic_gemm_args {
   int32_t bias_axis;  /* 0: bias[n]   1: bias[m] */
   int32_t in_dtype;   /* dtype of A and W */
   int32_t out_dtype;  /* dtype of out */
+  int32_t tile_cfg;   /* bf16 only: tile configuration 0..11 (see csrc/gemm_bf16.hip), -1 = built-in choice */
 } odic_gemm_args;
 int odic_gemm(const odic_gemm_args* args, void* stream);
 
-/* Tuning / test hook: force the bf16 tile configuration (0: 128x64, 1: 128x128, 2: 256x256,
- * -1: automatic choice).  Process-global; not for production use. */
+/* Test hook: force the bf16 tile configuration for every call that passes tile_cfg = -1
+ * (-1 restores the built-in choice).  Process-global; not for production use. */
 void odic_gemm_bf16_force_config(int cfg);
 
 /* ---------------------------------------------------------------------------------------------
@@ -99,7 +100,7 @@ int odic_patch_merge_layernorm(const float* x, const float* gamma, const float* 
 
 /* PatchEmbed: Conv2d(in_chans→C, k=s=patch) + flatten + LayerNorm(C)
  * (swin_transformer_mod.py:511-519).  img fp32 [B,in_chans,H,W]; w fp32 [C,in_chans*patch*patch];
- * out fp32 [B,(H/patch)*(W/patch),C]. */
+ * out fp32 [B,(H/patch)*(W/patch),C].  patch == 4, C in {64,96,128,192,256}, in_chans*16 <= 64. */
 int odic_patch_embed(const float* img, const float* w, const float* b, const float* gamma,
                      const float* beta, float* out, int32_t B, int32_t in_chans, int32_t H,
                      int32_t W, int32_t patch, int32_t C, float eps, void* stream);

@@ -16,17 +16,18 @@
 //     the ds_read_b128 fragment reads (rule 21: both sides or neither).
 //   * two LDS stages: the DMA of K-tile t+1 is in flight while tile t feeds the MFMAs; one
 //     s_waitcnt vmcnt(0) + barrier per K-tile.
-//   * epilogue through LDS: each wave parks 16 x TN fp32 accumulator rows in its own LDS slab and
-//     reads them back row-contiguous, so bias / activation / fp32 residual / output all move as
-//     16-byte (fp32) or 8-byte (bf16) per-lane vectors on full rows instead of 2-4-byte scatters.
-//   * XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); each XCD gets a
-//     contiguous run of tiles, N fastest, so concurrently resident tiles share A and W panels.
+//   * operands are SWAPPED in the MFMA (A-slot = W fragment, B-slot = activation fragment): the
+//     accumulator tile is then Cᵀ, i.e. each lane holds 4 CONSECUTIVE OUTPUT COLUMNS of one output
+//     row, so bias / activation / fp32 residual / output move as 16-byte (fp32) or 8-byte (bf16)
+//     per-lane vectors straight from the accumulator registers — no LDS staging, no shuffles.
+//   * XCD-aware 2-D tile partition: blocks b, b+8, ... share an XCD (and its 4 MiB L2); each XCD
+//     owns a PM x PN rectangle of the tile grid chosen so that its W sub-panel stays L2-resident
+//     while its A panels stream through once (PMC: L2 hit rate 70 % → see profiles/).
 //   * rows/cols beyond M/N are clamped on load (valid memory, discarded on store).
 #include "odic_common.h"
 
 namespace {
 
-constexpr int BK = 64;
 
 struct Params {
   const bf16_raw* A; const bf16_raw* W; const float* bias; const float* residual; void* out;
@@ -35,50 +36,67 @@ struct Params {
   long strideA, strideW, strideBias, strideR, strideC;
   float alpha; int act; int bias_axis;
   int tiles_m, tiles_n;
+  int pm, pn;          // XCD partition of the tile grid, pm * pn == 8
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int NWM, int NWN, int MI, int NI, typename OutT>
+// 16-byte-chunk swizzle inside an LDS row.  BK = 64 (128-byte rows, 8 chunks): chunk ^ (row & 7).
+// BK = 32 (64-byte rows, 4 chunks; 4 rows share a 256-byte bank row): chunk ^ f((row >> 2) & 3) with
+// f = {0, 2, 3, 1}, which makes every 16-lane service group of ds_read_b128 hit 16 distinct slots.
+template <int BK> __device__ __forceinline__ int swz(int chunk, int row) {
+  if constexpr (BK == 64) return chunk ^ (row & 7);
+  else return chunk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3);
+}
+
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK, typename OutT>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) {
   constexpr int NW = NWM * NWN;
-  constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16, TN = NI * 16;
+  constexpr int ROWB = BK * 2;                 // bytes per LDS row
+  constexpr int RPI = 1024 / ROWB;             // rows per 1-KiB DMA instruction
+  constexpr int CPR = ROWB / 16;               // 16-byte chunks per row
+  constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
   constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
-  constexpr int A_INSTR = BM / 8 / NW, W_INSTR = BN / 8 / NW;      // 1-KiB DMA instructions per wave
-  constexpr int EP_LD = TN + 4;                                      // fp32 words per staged row
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
-  static_assert(NW * 16 * EP_LD * 4 <= 2 * STAGE, "epilogue slabs must fit in the pipeline LDS");
+  constexpr int A_INSTR = BM / RPI / NW, W_INSTR = BN / RPI / NW;  // 1-KiB DMA instructions per wave
+  static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "tile rows must split evenly over the waves");
+  constexpr int G = A_INSTR + W_INSTR;                                 // LDS-DMA instructions per wave per K-tile
+  constexpr int D = NSTAGE - 1;                                        // prefetch distance in K-tiles
   extern __shared__ __attribute__((aligned(16))) char lds[];          // stage0 {A,W} | stage1 {A,W}
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / NWN, wn = wave % NWN;
 
-  const int ntiles = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
+  // XCD x = blockIdx % 8 owns tile rows [r0,r1) x cols [c0,c1); inside the rectangle tiles run N-fastest
+  int tm, tn;
   {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int xm = xcd / p.pn, xn = xcd - xm * p.pn;
+    const int r0 = xm * p.tiles_m / p.pm, r1 = (xm + 1) * p.tiles_m / p.pm;
+    const int c0 = xn * p.tiles_n / p.pn, c1 = (xn + 1) * p.tiles_n / p.pn;
+    const int w = c1 - c0;
+    if (idx >= (r1 - r0) * w) return;             // rectangles differ by at most one row/col of tiles
+    const int lr = idx / w;
+    tm = r0 + lr; tn = c0 + (idx - lr * w);
   }
-  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const long bz = blockIdx.z;
   const bf16_raw* A = p.A + bz * p.strideA;
   const bf16_raw* W = p.W + bz * p.strideW;
 
-  // ---- LDS-DMA source addresses: instruction i of this wave fills rows (i*NW+wave)*8 .. +7
-  const int srow = lane >> 3;
-  const int schunk = (lane & 7) ^ srow;         // logical 16-byte chunk this lane must fetch
+  // ---- LDS-DMA source addresses: instruction i of this wave fills rows (i*NW+wave)*RPI .. +RPI-1
+  const int srow = lane / CPR;
+  const int schunk = swz<BK>(lane % CPR, srow);  // logical 16-byte chunk this lane must fetch
   const bf16_raw* a_src[A_INSTR];
   const bf16_raw* w_src[W_INSTR];
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
-    const int row = (i * NW + wave) * 8 + srow;
+    const int row = (i * NW + wave) * RPI + srow;
     a_src[i] = A + (long)min(m0 + row, p.M - 1) * p.lda + schunk * 8;
   }
 #pragma unroll
   for (int i = 0; i < W_INSTR; ++i) {
-    const int row = (i * NW + wave) * 8 + srow;
+    const int row = (i * NW + wave) * RPI + srow;
     w_src[i] = W + (long)min(n0 + row, p.N - 1) * p.ldw + schunk * 8;
   }
 
@@ -102,107 +120,120 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
   const int nk = p.K / BK;
   const int frow = lane & 15, fq = lane >> 4;
 
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // Pipeline: tiles kt+1 .. kt+D-1 stay in flight across the barrier (counted vmcnt: the wave's own
+  // DMA groups retire in order, G instructions per tile; the raw s_barrier carries no implicit
+  // vmcnt(0) drain).  After the barrier every wave's share of tile kt has landed AND every wave has
+  // finished reading tile kt-1, whose buffer the prefetch of tile kt+D then overwrites.
+#pragma unroll
+  for (int t = 0; t < D; ++t)
+    if (t < nk) stage(t, t);
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const int ahead = min(D - 1, nk - 1 - kt);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + D < nk) stage((kt + D) % NSTAGE, kt + D);
 
-    const char* la = lds + cur * STAGE + (wm * MI * 16 + frow) * 128;
-    const char* lw = lds + cur * STAGE + A_BYTES + (wn * NI * 16 + frow) * 128;
+    const int cur = kt % NSTAGE;
+    const char* la = lds + cur * STAGE + (wm * MI * 16 + frow) * ROWB;
+    const char* lw = lds + cur * STAGE + A_BYTES + (wn * NI * 16 + frow) * ROWB;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < BK / 32; ++kk) {
       bf16x8_t af[MI], wf[NI];
-      const int chunk = ((kk * 4 + fq) ^ (frow & 7)) << 4;
+      const int chunk = swz<BK>(kk * 4 + fq, frow) << 4;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = *(const bf16x8_t*)(la + mi * 16 * 128 + chunk);
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *(const bf16x8_t*)(la + mi * 16 * ROWB + chunk);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const bf16x8_t*)(lw + ni * 16 * 128 + chunk);
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const bf16x8_t*)(lw + ni * 16 * ROWB + chunk);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], wf[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
-
-  // ---- epilogue.  C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+  // ---- epilogue.  With the operands swapped the 16x16 accumulator is Cᵀ: lane (frow, fq) register j
+  //      holds C[m = frow][n = 4·fq + j]  →  one 4-wide row vector per (mi, ni).
   const float* bias = p.bias ? p.bias + bz * p.strideBias : nullptr;
   const float* resid = p.residual ? p.residual + bz * p.strideR : nullptr;
   OutT* out = (OutT*)p.out + bz * p.strideC;
-  float* slab = (float*)lds + wave * 16 * EP_LD;          // private to this wave
-  constexpr int VPR = TN / 4;                              // float4 vectors per staged row
-  constexpr int RPP = 64 / VPR;                            // rows per read-back pass
-  const int rcol = (lane % VPR) * 4, rrow = lane / VPR;
-  const int col = n0 + wn * TN + rcol;
-  const bool vec_ok = (col + 3 < p.N) && ((p.ldc & 3) == 0) && (!resid || (p.ldr & 3) == 0);
-  float4 bcol = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (bias && !p.bias_axis) {
-    bcol.x = col + 0 < p.N ? bias[col + 0] : 0.f; bcol.y = col + 1 < p.N ? bias[col + 1] : 0.f;
-    bcol.z = col + 2 < p.N ? bias[col + 2] : 0.f; bcol.w = col + 3 < p.N ? bias[col + 3] : 0.f;
+  const bool ld_ok = ((p.ldc & 3) == 0) && (!resid || (p.ldr & 3) == 0);
+  float4 bcol[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int col = n0 + (wn * NI + ni) * 16 + fq * 4;
+    bcol[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && !p.bias_axis) {
+      bcol[ni].x = col + 0 < p.N ? bias[col + 0] : 0.f; bcol[ni].y = col + 1 < p.N ? bias[col + 1] : 0.f;
+      bcol[ni].z = col + 2 < p.N ? bias[col + 2] : 0.f; bcol[ni].w = col + 3 < p.N ? bias[col + 3] : 0.f;
+    }
   }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
+    const int row = m0 + (wm * MI + mi) * 16 + frow;
+    if (row >= p.M) continue;
+    const float brow = (bias && p.bias_axis) ? bias[row] : 0.f;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) slab[(fq * 4 + j) * EP_LD + ni * 16 + frow] = acc[mi][ni][j];
-    __syncthreads();
-#pragma unroll
-    for (int pass = 0; pass < 16 / RPP; ++pass) {
-      const int r = pass * RPP + rrow;
-      const int row = m0 + (wm * MI + mi) * 16 + r;
-      if (row < p.M) {
-        float4 v = *(const float4*)(slab + r * EP_LD + rcol);
-        v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
-        if (bias) {
-          if (p.bias_axis) { const float b = bias[row]; v.x += b; v.y += b; v.z += b; v.w += b; }
-          else { v.x += bcol.x; v.y += bcol.y; v.z += bcol.z; v.w += bcol.w; }
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = n0 + (wn * NI + ni) * 16 + fq * 4;
+      if (col >= p.N) continue;
+      float4 v;
+      v.x = apply_act<true>(acc[mi][ni][0] * p.alpha + bcol[ni].x + brow, p.act);
+      v.y = apply_act<true>(acc[mi][ni][1] * p.alpha + bcol[ni].y + brow, p.act);
+      v.z = apply_act<true>(acc[mi][ni][2] * p.alpha + bcol[ni].z + brow, p.act);
+      v.w = apply_act<true>(acc[mi][ni][3] * p.alpha + bcol[ni].w + brow, p.act);
+      if (ld_ok && col + 3 < p.N) {
+        if (resid) {
+          const float4 rr = *(const float4*)(resid + (long)row * p.ldr + col);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
-        v.x = apply_act<true>(v.x, p.act); v.y = apply_act<true>(v.y, p.act);
-        v.z = apply_act<true>(v.z, p.act); v.w = apply_act<true>(v.w, p.act);
-        if (vec_ok) {
-          if (resid) {
-            const float4 rr = *(const float4*)(resid + (long)row * p.ldr + col);
-            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-          }
-          OutT* dst = out + (long)row * p.ldc + col;
-          if constexpr (sizeof(OutT) == 4) {
-            *(float4*)dst = v;
-          } else {
-            ushort4 pk;
-            pk.x = f32_to_bf16(v.x); pk.y = f32_to_bf16(v.y); pk.z = f32_to_bf16(v.z); pk.w = f32_to_bf16(v.w);
-            *(ushort4*)dst = pk;
-          }
+        OutT* dst = out + (long)row * p.ldc + col;
+        if constexpr (sizeof(OutT) == 4) {
+          *(float4*)dst = v;
         } else {
-          const float vv[4] = {v.x, v.y, v.z, v.w};
+          ushort4 pk;
+          pk.x = f32_to_bf16(v.x); pk.y = f32_to_bf16(v.y); pk.z = f32_to_bf16(v.z); pk.w = f32_to_bf16(v.w);
+          *(ushort4*)dst = pk;
+        }
+      } else {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (col + e < p.N) {
-              float x = vv[e];
-              if (resid) x += resid[(long)row * p.ldr + col + e];
-              store_from_f32<OutT>(out + (long)row * p.ldc + col + e, x);
-            }
+        for (int e = 0; e < 4; ++e) {
+          if (col + e < p.N) {
+            float x = vv[e];
+            if (resid) x += resid[(long)row * p.ldr + col + e];
+            store_from_f32<OutT>(out + (long)row * p.ldc + col + e, x);
           }
         }
       }
     }
-    __syncthreads();
   }
 }
 
-template <int NWM, int NWN, int MI, int NI>
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK = 64>
 int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
   constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
-  constexpr int SHMEM = 2 * (BM + BN) * BK * 2;
+  constexpr int SHMEM = NSTAGE * (BM + BN) * BK * 2;
+  if (p.K % BK != 0) return ODIC_EINVAL;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
-  dim3 grid(p.tiles_m * p.tiles_n, 1, batch), block(64 * NWM * NWN);
-  auto kb = gemm_bf16_nt_kernel<NWM, NWN, MI, NI, bf16_raw>;
-  auto kf = gemm_bf16_nt_kernel<NWM, NWN, MI, NI, float>;
+  // XCD partition: fewest column parts whose W sub-panel (N/pn x K bf16) fits ~2.5 MiB of the 4 MiB L2
+  int pn = 1;
+  while (pn < 8 && pn * 2 <= p.tiles_n && (double)p.N / pn * p.K * 2.0 > 2.5 * 1024 * 1024) pn *= 2;
+  int pm = 8 / pn;
+  while (pm > p.tiles_m && pm > 1) { pm /= 2; pn *= 2; }
+  if (pn > p.tiles_n) { pn = 1; pm = 8; while (pm > p.tiles_m && pm > 1) pm /= 2; pn = 8 / pm; }
+  p.pm = pm; p.pn = pn;
+  int max_rect = 0;
+  for (int xm = 0; xm < pm; ++xm)
+    for (int xn = 0; xn < pn; ++xn) {
+      const int r = ((xm + 1) * p.tiles_m / pm - xm * p.tiles_m / pm) * ((xn + 1) * p.tiles_n / pn - xn * p.tiles_n / pn);
+      if (r > max_rect) max_rect = r;
+    }
+  dim3 grid(8 * max_rect, 1, batch), block(64 * NWM * NWN);
+  auto kb = gemm_bf16_nt_kernel<NWM, NWN, MI, NI, NSTAGE, BK, bf16_raw>;
+  auto kf = gemm_bf16_nt_kernel<NWM, NWN, MI, NI, NSTAGE, BK, float>;
   if (SHMEM > 64 * 1024) {
     static bool done = false;       // idempotent; racing first calls set the same value
     if (!done) {
@@ -223,7 +254,7 @@ int g_force_cfg = -1;      // test / tuning hook: odic_gemm_bf16_force_config()
 extern "C" void odic_gemm_bf16_force_config(int cfg) { g_force_cfg = cfg; }
 
 int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
-  if (a->K % BK != 0 || a->lda % 8 != 0 || a->ldw % 8 != 0) return ODIC_EINVAL;
+  if (a->K % 64 != 0 || a->lda % 8 != 0 || a->ldw % 8 != 0) return ODIC_EINVAL;
   if (((uintptr_t)a->A & 15) || ((uintptr_t)a->W & 15)) return ODIC_EINVAL;
   if ((a->strideA % 8) || (a->strideW % 8)) return ODIC_EINVAL;
   Params p;
@@ -237,7 +268,7 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
   // rounds (256 CUs x 3 / 2 / 1 blocks for the 128x64 / 128x128 / 256x256 tiles, set by their LDS
   // footprints); relative per-tile costs 1 : 1.38 : 2.6 were measured on MI355X over the Swin-L
   // shapes (tools/gemm_tune.py; profiles/r01_gemm_tile_sweep.txt).
-  int cfg = g_force_cfg;
+  int cfg = a->tile_cfg >= 0 ? a->tile_cfg : g_force_cfg;
   if (cfg < 0) {
     auto rounds = [&](int bm, int bn, int slots) {
       const long t = (long)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn) * a->batch;
@@ -248,9 +279,18 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     cfg = (c0 <= c1 && c0 <= c2) ? 0 : (c1 <= c2 ? 1 : 2);
   }
   switch (cfg) {
-    case 0: return launch_cfg<2, 2, 4, 2>(p, a->out_dtype, a->batch, stream);     // 128 x 64
-    case 1: return launch_cfg<2, 2, 4, 4>(p, a->out_dtype, a->batch, stream);     // 128 x 128
-    case 2: return launch_cfg<2, 4, 8, 4>(p, a->out_dtype, a->batch, stream);     // 256 x 256
+    case 0: return launch_cfg<2, 2, 4, 2, 2>(p, a->out_dtype, a->batch, stream);     // 128 x 64, 2 stages
+    case 1: return launch_cfg<2, 2, 4, 4, 2>(p, a->out_dtype, a->batch, stream);     // 128 x 128
+    case 2: return launch_cfg<2, 4, 8, 4, 2>(p, a->out_dtype, a->batch, stream);     // 256 x 256
+    case 3: return launch_cfg<2, 2, 4, 2, 3>(p, a->out_dtype, a->batch, stream);     // 128 x 64, 3 stages
+    case 4: return launch_cfg<2, 2, 4, 4, 3>(p, a->out_dtype, a->batch, stream);     // 128 x 128, 3 stages
+    case 5: return launch_cfg<4, 2, 4, 4, 3>(p, a->out_dtype, a->batch, stream);     // 256 x 128, 3 stages (144 KiB)
+    case 6: return launch_cfg<2, 2, 4, 2, 4>(p, a->out_dtype, a->batch, stream);     // 128 x 64, 4 stages
+    case 7: return launch_cfg<4, 2, 4, 4, 2, 32>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32 (48 KiB)
+    case 8: return launch_cfg<2, 2, 4, 4, 2, 32>(p, a->out_dtype, a->batch, stream); // 128 x 128 x 32 (32 KiB)
+    case 9: return launch_cfg<2, 4, 8, 4, 2, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32 (64 KiB)
+    case 10: return launch_cfg<4, 2, 4, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32, 3 stages (72 KiB)
+    case 11: return launch_cfg<2, 4, 8, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32, 3 stages (96 KiB)
     default: return ODIC_EINVAL;
   }
 }

@@ -112,11 +112,13 @@ int launch_ln(const float* x, long ldx, const float* g, const float* b, void* ou
 }
 
 // ---------------------------------------------------------------------------------------------
-// patch embed: one wave per token; the K = in_chans*patch² inputs of the token are broadcast by
-// shuffles, each lane owns output channels lane, lane+64, ... (<= 8 per lane → C <= 512).
-// Weights are read through L1/L2 (C*K*4 B = 36 KiB for Swin-L, shared by every wave).
+// patch embed: a block of 256 threads owns 64 consecutive tokens.  Inputs (64 x K, float4 loads along
+// the patch rows, coalesced over consecutive tokens) and the transposed weights [K][C] sit in LDS;
+// thread (token = tid & 63, group = tid >> 6) accumulates C/4 output channels with broadcast weight
+// reads, LayerNorm moments are combined across the 4 channel groups through LDS, and the normalised
+// 64 x C tile leaves through an LDS slab as one linear, fully coalesced copy.
 // ---------------------------------------------------------------------------------------------
-template <int CPL>
+template <int CPT>     // channels per thread; C == 4 * CPT exactly
 __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ img,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ bias,
@@ -124,56 +126,88 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
                                                           const float* __restrict__ beta, float* __restrict__ out,
                                                           int B, int in_chans, int H, int W, int patch, int C,
                                                           float eps) {
-  extern __shared__ float wt[];            // [K][C] transposed weights: lanes read consecutive c
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int K = in_chans * patch * patch;
-  for (int i = threadIdx.x; i < C * K; i += blockDim.x) {
-    const int c = i / K, k = i - c * K;
-    wt[k * C + c] = w[i];
+  constexpr int cpt = CPT;
+  float* wt = sm;                          // [K][C]
+  float* xin = wt + K * C;                 // [K][64]
+  float* red = xin + K * 64;               // [4][64]
+  float* slab = sm;                        // [64][C+1]  — reuses the weight/input area after the FMAs
+  const int tid = threadIdx.x, token = tid & 63, grp = tid >> 6;
+  const int gh = H / patch, gw = W / patch;
+  const int per_img = gh * gw;
+  const long ntok = (long)B * per_img;
+  const long tok0 = (long)blockIdx.x * 64;
+  const int b0 = (int)(tok0 / per_img);                 // one 64-bit divide per block (wave-uniform)
+  const int r0 = (int)(tok0 - (long)b0 * per_img);
+  const int nvalid = (int)min((long)64, ntok - tok0);
+
+  // weights, transposed on the fly: lanes walk c (conflict-free LDS writes), 32-bit index math only
+  const int CK = C * K;
+  for (int i = tid; i < CK; i += 256) {
+    const int k = i / C, c = i - k * C;
+    wt[i] = w[c * K + k];
+  }
+  // input rows: segment s = (channel, patch row) holds 4 contiguous floats per token
+  const int nseg = in_chans * patch;
+  for (int i = tid; i < nseg * 64; i += 256) {
+    const int t = i & 63, sgm = i >> 6;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < nvalid) {
+      int r = r0 + t, b = b0;
+      if (r >= per_img) { r -= per_img; ++b; }           // a 64-token block spans at most two images
+      const int ph = r / gw, pw = r - ph * gw;
+      const int c = sgm / patch, kh = sgm - c * patch;
+      v = *(const float4*)(img + (((long)b * in_chans + c) * H + ph * patch + kh) * W + pw * patch);
+    }
+    const int k0 = sgm * patch;
+    xin[(k0 + 0) * 64 + t] = v.x; xin[(k0 + 1) * 64 + t] = v.y;
+    xin[(k0 + 2) * 64 + t] = v.z; xin[(k0 + 3) * 64 + t] = v.w;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int gh = H / patch, gw = W / patch;
-  const long ntok = (long)B * gh * gw;
-  const long tok0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;    // 8 tokens per wave
-  for (int it = 0; it < 8; ++it) {
-    const long tok = tok0 + it;
-    if (tok >= ntok) return;
-    const int b = tok / (gh * gw);
-    const int r = tok - (long)b * gh * gw;
-    const int ph = r / gw, pw = r - ph * gw;
-    // lane k (< K) loads input element k = (c, kh, kw)
-    float xin = 0.f;
-    if (lane < K) {
-      const int c = lane / (patch * patch), rem = lane - c * patch * patch;
-      const int kh = rem / patch, kw = rem - kh * patch;
-      xin = img[(((long)b * in_chans + c) * H + ph * patch + kh) * W + pw * patch + kw];
+
+  float acc[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) acc[c] = bias[grp * cpt + c];
+  for (int k = 0; k < K; ++k) {
+    const float xv = xin[k * 64 + token];
+    const float4* wr = (const float4*)(wt + k * C + grp * cpt);     // wave-uniform address: LDS broadcast
+    float4 wv[CPT / 4];
+#pragma unroll
+    for (int c = 0; c < CPT / 4; ++c) wv[c] = wr[c];                  // all reads in flight before the FMAs
+#pragma unroll
+    for (int c = 0; c < CPT / 4; ++c) {
+      acc[4 * c + 0] = fmaf(xv, wv[c].x, acc[4 * c + 0]); acc[4 * c + 1] = fmaf(xv, wv[c].y, acc[4 * c + 1]);
+      acc[4 * c + 2] = fmaf(xv, wv[c].z, acc[4 * c + 2]); acc[4 * c + 3] = fmaf(xv, wv[c].w, acc[4 * c + 3]);
     }
-    float acc[CPL];
+  }
+  float s = 0.f;
 #pragma unroll
-    for (int t = 0; t < CPL; ++t) {
-      const int c = lane + 64 * t;
-      acc[t] = c < C ? bias[c] : 0.f;
-    }
-    for (int k = 0; k < K; ++k) {
-      const float xv = __shfl(xin, k, 64);
+  for (int c = 0; c < CPT; ++c) s += acc[c];
+  red[grp * 64 + token] = s;
+  __syncthreads();
+  const float mean = (red[token] + red[64 + token] + red[128 + token] + red[192 + token]) / (float)C;
+  __syncthreads();
+  float q = 0.f;
 #pragma unroll
-      for (int t = 0; t < CPL; ++t) {
-        const int c = lane + 64 * t;
-        if (c < C) acc[t] = fmaf(xv, wt[k * C + c], acc[t]);
-      }
-    }
-    float s = 0.f;
+  for (int c = 0; c < CPT; ++c) { const float dlt = acc[c] - mean; q += dlt * dlt; }
+  red[grp * 64 + token] = q;
+  __syncthreads();
+  const float rstd = rsqrtf((red[token] + red[64 + token] + red[128 + token] + red[192 + token]) / (float)C + eps);
+  __syncthreads();                         // everyone is done with wt / xin / red: the slab may overwrite them
 #pragma unroll
-    for (int t = 0; t < CPL; ++t) if (lane + 64 * t < C) s += acc[t];
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int t = 0; t < CPL; ++t) if (lane + 64 * t < C) { const float d = acc[t] - mean; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-#pragma unroll
-    for (int t = 0; t < CPL; ++t) {
-      const int c = lane + 64 * t;
-      if (c < C) out[tok * C + c] = (acc[t] - mean) * rstd * gamma[c] + beta[c];
+  for (int c = 0; c < CPT; ++c) {
+    const int ch = grp * cpt + c;
+    slab[token * (C + 1) + ch] = (acc[c] - mean) * rstd * gamma[ch] + beta[ch];
+  }
+  __syncthreads();
+  // 64 x C tile → global: row t = grp + 4r, lane = float4 column; rows are contiguous in `out`
+  float* dst = out + tok0 * C;
+  const int C4 = C >> 2;
+  for (int t = grp; t < nvalid; t += 4) {
+    for (int c4 = token; c4 < C4; c4 += 64) {
+      const float* sp = slab + t * (C + 1) + 4 * c4;
+      *(float4*)(dst + (long)t * C + 4 * c4) = make_float4(sp[0], sp[1], sp[2], sp[3]);
     }
   }
 }
@@ -230,13 +264,28 @@ extern "C" int odic_patch_embed(const float* img, const float* w, const float* b
                                 int32_t W, int32_t patch, int32_t C, float eps, void* stream) {
   if (!img || !w || !b || !gamma || !beta || !out) return ODIC_ENULL;
   const int K = in_chans * patch * patch;
-  if (B <= 0 || K > 64 || C > 512 || H % patch || W % patch) return ODIC_EINVAL;
+  if (B <= 0 || K > 64 || C > 256 || H % patch || W % patch) return ODIC_EINVAL;
   const long ntok = (long)B * (H / patch) * (W / patch);
-  dim3 grid((unsigned)((ntok + 31) / 32)), block(256);
-  const size_t shmem = (size_t)C * K * sizeof(float);
+  if (patch != 4 || (C & 15) || (W & 3) || ((uintptr_t)img & 15)) return ODIC_EUNSUPPORTED;
+  dim3 grid((unsigned)((ntok + 63) / 64)), block(256);
+  const size_t main_words = (size_t)C * K + K * 64 + 256, slab_words = (size_t)64 * (C + 1);
+  const size_t shmem = (main_words > slab_words ? main_words : slab_words) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  if (C <= 128) hipLaunchKernelGGL(patch_embed_kernel<2>, grid, block, shmem, s, img, w, b, gamma, beta, out, B, in_chans, H, W, patch, C, eps);
-  else if (C <= 256) hipLaunchKernelGGL(patch_embed_kernel<4>, grid, block, shmem, s, img, w, b, gamma, beta, out, B, in_chans, H, W, patch, C, eps);
-  else hipLaunchKernelGGL(patch_embed_kernel<8>, grid, block, shmem, s, img, w, b, gamma, beta, out, B, in_chans, H, W, patch, C, eps);
+  auto launch = [&](auto kern) {
+    static bool raised = false;          // one flag per kernel instantiation; first call is never inside a capture
+    if (!raised) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      raised = true;
+    }
+    hipLaunchKernelGGL(kern, grid, block, shmem, s, img, w, b, gamma, beta, out, B, in_chans, H, W, patch, C, eps);
+  };
+  switch (C) {
+    case 64: launch(patch_embed_kernel<16>); break;
+    case 96: launch(patch_embed_kernel<24>); break;
+    case 128: launch(patch_embed_kernel<32>); break;
+    case 192: launch(patch_embed_kernel<48>); break;
+    case 256: launch(patch_embed_kernel<64>); break;
+    default: return ODIC_EUNSUPPORTED;       // Swin embed dims: 96 (T/S), 128 (B), 192 (L)
+  }
   return odic_launch_status();
 }

@@ -80,6 +80,54 @@ def dtype_code(dt: torch.dtype) -> int:
 
 
 # ----------------------------------------------------------------------------------------------
+# bf16 GEMM tile autotuning: "measure, don't guess".  While `autotune()` is active (the eager warm-up
+# pass of a pipeline, never inside a stream capture) the first call of every distinct problem shape
+# times the candidate tile configurations with HIP events on scratch outputs and remembers the
+# fastest; later calls (including the captured ones) reuse the choice.
+_TILE_CHOICE: dict = {}
+_TUNING = False
+_TILE_CANDIDATES = (0, 1, 2, 7, 10)
+
+
+class autotune:
+    def __enter__(self):
+        global _TUNING
+        self._prev, _TUNING = _TUNING, True
+        return _TILE_CHOICE
+
+    def __exit__(self, *exc):
+        global _TUNING
+        _TUNING = self._prev
+        return False
+
+
+def _tune_gemm(args: "_hip.GemmArgs", key, out: torch.Tensor) -> int:
+    lib = _hip.load()
+    scratch = torch.empty_like(out)
+    real_out = args.out
+    args.out = scratch.data_ptr()
+    best, best_ms = -1, float("inf")
+    try:
+        for cfg in _TILE_CANDIDATES:
+            args.tile_cfg = cfg
+            if lib.odic_gemm(C.byref(args), _stream()) != 0:
+                continue
+            lib.odic_gemm(C.byref(args), _stream())
+            st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st.record()
+            for _ in range(4):
+                lib.odic_gemm(C.byref(args), _stream())
+            en.record()
+            en.synchronize()
+            ms = st.elapsed_time(en)
+            if ms < best_ms:
+                best, best_ms = cfg, ms
+    finally:
+        args.out = real_out
+    _TILE_CHOICE[key] = best
+    return best
+
+
 def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
          residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
          alpha: float = 1.0, bias_axis: int = 0, out_dtype: Optional[torch.dtype] = None,
@@ -117,7 +165,15 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
         raise RuntimeError("residual must be fp32")
     a = _hip.GemmArgs(_p(A), _p(W), _p(bias), _p(residual), _p(out), M, N, K, lda, ldw, ldr or 0, ldc, batch,
                       strideA, strideW, strideBias, strideR, strideC, alpha, act, bias_axis,
-                      dtype_code(A.dtype), dtype_code(out.dtype))
+                      dtype_code(A.dtype), dtype_code(out.dtype), -1)
+    if A.dtype == torch.bfloat16:
+        key = (M, N, K, batch, out.dtype, act, residual is not None)
+        cfg = _TILE_CHOICE.get(key)
+        if cfg is None and _TUNING and _PROFILE is None and ldc == N and batch == 1 \
+                and not torch.cuda.is_current_stream_capturing():
+            cfg = _tune_gemm(a, key, out)
+        if cfg is not None:
+            a.tile_cfg = cfg
     isz, osz = A.element_size(), out.element_size()
     nbytes = batch * ((M * K if strideA or batch == 1 else M * K / batch) * isz +
                       (N * K if strideW or batch == 1 else N * K / batch) * isz + M * N * osz +

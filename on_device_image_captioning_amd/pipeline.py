@@ -24,12 +24,18 @@ from .captioning_model import CaptioningModel
 
 
 class CaptionPipeline:
-    """Two HIP streams: the encode graph of batch i+1 (compute-bound, fills the chip) runs while the
-    decode-step graph of batch i (latency-bound, a few dozen workgroups per kernel) is replayed.
-    `submit()` only enqueues; `collect()` returns the captions of the oldest outstanding batch."""
+    """Software pipeline over consecutive batches on HIP streams:
+
+        s_enc      encode graph of batch i+1          (compute-bound, fills the chip)
+        s_dec[0]   decode-step graph x(T-1), batch i   \\  ~40 tiny dependent kernels per step: latency-bound,
+        s_dec[1]   decode-step graph x(T-1), batch i-1 //  so two chains in flight hide each other's waits
+
+    `submit()` only enqueues; `collect()` returns the captions of the oldest outstanding batch.  Every
+    batch is still processed exactly as in the reference (batch B through encoder and search); only
+    the scheduling across batches is overlapped."""
 
     def __init__(self, model: CaptioningModel, batch: int, beam_size: int, max_seq_len: int, sos_idx: int,
-                 eos_idx: int, use_graphs: bool = True, done_poll: int = 0):
+                 eos_idx: int, use_graphs: bool = True, done_poll: int = 0, decode_lanes: int = 2):
         """done_poll = 0: never look at the `done` flag (fixed work per batch — benchmark mode with
         weights that never emit EOS); n > 0: host checks every n steps and stops early."""
         self.model, self.B, self.k = model, batch, beam_size
@@ -37,6 +43,8 @@ class CaptionPipeline:
         self.T = self.steps + 1
         self.sos, self.eos = sos_idx, eos_idx
         self.done_poll = done_poll
+        self.D = max(1, decode_lanes)
+        self.R = self.D + 1                                        # batches that may be outstanding
         swin, cap = model._engines()
         self.swin, self.cap = swin, cap
         g, dv = cap.g, cap.device
@@ -47,27 +55,33 @@ class CaptionPipeline:
         self.enc_len = torch.full((batch,), S, dtype=torch.int32, device=dv)
         kvshape = (batch, S, 2 * g.N_dec * g.d_model)
         self.kv_stage = torch.empty(kvshape, dtype=torch.float32, device=dv)    # written by the encode graph
-        self.kv = torch.empty(kvshape, dtype=torch.float32, device=dv)          # read by the decode steps
-        self.state = cap.new_state(batch, beam_size, self.T, self.kv, self.enc_len)
-        self.order = torch.empty(batch, beam_size, dtype=torch.int32, device=dv)
-        self.score = torch.empty(batch, beam_size, dtype=torch.float32, device=dv)
-        self.s_enc, self.s_dec = torch.cuda.Stream(device=dv), torch.cuda.Stream(device=dv)
+        self.kv = [torch.empty(kvshape, dtype=torch.float32, device=dv) for _ in range(self.D)]
+        self.states = [cap.new_state(batch, beam_size, self.T, self.kv[l], self.enc_len) for l in range(self.D)]
+        self.order = [torch.empty(batch, beam_size, dtype=torch.int32, device=dv) for _ in range(self.D)]
+        self.score = [torch.empty(batch, beam_size, dtype=torch.float32, device=dv) for _ in range(self.D)]
+        self.s_enc = torch.cuda.Stream(device=dv)
+        self.s_dec = [torch.cuda.Stream(device=dv) for _ in range(self.D)]
         self.ev_enc = torch.cuda.Event()
         self.ev_kv_taken = torch.cuda.Event()
         self.ev_kv_taken.record()
-        # results ring (device) + pinned host mirrors; depth 2 = one batch decoding, one being read
-        self.out_tok = [torch.zeros(batch, self.T, dtype=torch.int32, device=dv) for _ in range(2)]
-        self.out_len = [torch.zeros(batch, dtype=torch.int32, device=dv) for _ in range(2)]
-        self.host_tok = [torch.zeros(batch, self.T, dtype=torch.int32).pin_memory() for _ in range(2)]
-        self.host_len = [torch.zeros(batch, dtype=torch.int32).pin_memory() for _ in range(2)]
-        self.ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+        # results ring (device) + pinned host mirrors
+        self.out_tok = [torch.zeros(batch, self.T, dtype=torch.int32, device=dv) for _ in range(self.R)]
+        self.out_len = [torch.zeros(batch, dtype=torch.int32, device=dv) for _ in range(self.R)]
+        self.host_tok = [torch.zeros(batch, self.T, dtype=torch.int32).pin_memory() for _ in range(self.R)]
+        self.host_len = [torch.zeros(batch, dtype=torch.int32).pin_memory() for _ in range(self.R)]
+        self.ev_done = [torch.cuda.Event() for _ in range(self.R)]
         self._submitted = self._collected = 0
         self.g_enc: Optional[torch.cuda.CUDAGraph] = None
-        self.g_step: Optional[torch.cuda.CUDAGraph] = None
+        self.g_step: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.D
         if use_graphs:
             self._capture()
 
-    # -- the two captured regions ---------------------------------------------------------------
+    # compatibility with single-lane callers (tests, tools)
+    @property
+    def state(self):
+        return self.states[0]
+
+    # -- the captured regions -------------------------------------------------------------------
     def _encode(self) -> None:
         feats = self.swin.forward(self.img, out_dtype=self.cap.cdt)
         if self.cap.cdt == torch.bfloat16:
@@ -76,11 +90,11 @@ class CaptionPipeline:
         else:
             self.cap.project_kv(self.cap.encode(feats, self.enc_len), out=self.kv_stage)
 
-    def _step(self) -> None:
-        self.cap.beam_step(self.state, self.eos)
+    def _step(self, lane: int) -> None:
+        self.cap.beam_step(self.states[lane], self.eos)
 
-    def _reset(self) -> None:
-        st = self.state
+    def _reset(self, lane: int) -> None:
+        st = self.states[lane]
         st.tokens[:, :, 0] = self.sos
         st.logprobs[:, :, 0] = 0.0
         st.next_tok.fill_(self.sos)
@@ -90,29 +104,32 @@ class CaptionPipeline:
 
     def _capture(self) -> None:
         torch.cuda.synchronize()
-        with torch.cuda.stream(self.s_enc):                      # warm-up (allocator, lazy code load)
+        with torch.cuda.stream(self.s_enc), ops.autotune():      # warm-up: allocator, code load, tile autotune
             self._encode()
-        with torch.cuda.stream(self.s_dec):
-            self.s_dec.wait_stream(self.s_enc)
-            self.kv.copy_(self.kv_stage)
-            self._reset()
-            self._step()
+        for lane in range(self.D):
+            with torch.cuda.stream(self.s_dec[lane]):
+                self.s_dec[lane].wait_stream(self.s_enc)
+                self.kv[lane].copy_(self.kv_stage)
+                self._reset(lane)
+                self._step(lane)
         torch.cuda.synchronize()
         self.g_enc = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_enc, stream=self.s_enc):
             self._encode()
-        self._reset()
-        self.g_step = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_step, stream=self.s_dec):
-            self._step()
+        for lane in range(self.D):
+            self._reset(lane)
+            self.g_step[lane] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_step[lane], stream=self.s_dec[lane]):
+                self._step(lane)
         torch.cuda.synchronize()
 
     # -- public ---------------------------------------------------------------------------------
     def submit(self, images: torch.Tensor) -> None:
-        """Enqueue one batch on the two streams; never blocks the host (unless done_poll > 0)."""
-        if self._submitted - self._collected >= 2:
-            raise RuntimeError("at most two batches may be outstanding; call collect() first")
-        slot = self._submitted & 1
+        """Enqueue one batch; never blocks the host (unless done_poll > 0)."""
+        if self._submitted - self._collected >= self.R:
+            raise RuntimeError(f"at most {self.R} batches may be outstanding; call collect() first")
+        slot = self._submitted % self.R
+        lane = self._submitted % self.D
         cur = torch.cuda.current_stream()
         with torch.cuda.stream(self.s_enc):
             self.s_enc.wait_stream(cur)                          # `images` may have been produced there
@@ -123,21 +140,23 @@ class CaptionPipeline:
             else:
                 self._encode()
             self.ev_enc.record()
-        with torch.cuda.stream(self.s_dec):
-            self.s_dec.wait_event(self.ev_enc)
-            self.kv.copy_(self.kv_stage)
+        sd = self.s_dec[lane]
+        with torch.cuda.stream(sd):
+            sd.wait_event(self.ev_enc)
+            self.kv[lane].copy_(self.kv_stage)
             self.ev_kv_taken.record()
-            self._reset()
+            self._reset(lane)
+            st = self.states[lane]
             for t in range(self.steps):
-                if self.g_step is not None:
-                    self.g_step.replay()
+                if self.g_step[lane] is not None:
+                    self.g_step[lane].replay()
                 else:
-                    self._step()
+                    self._step(lane)
                 if self.done_poll and t >= 1 and (t + 1) % self.done_poll == 0 and t + 1 < self.steps \
-                        and int(self.state.done.item()):
+                        and int(st.done.item()):
                     break
-            ops.beam_finalize(self.state.beam_state, self.order, self.score, self.B, self.k)
-            toks, lens = self._best_tokens()
+            ops.beam_finalize(st.beam_state, self.order[lane], self.score[lane], self.B, self.k)
+            toks, lens = self._best_tokens(lane)
             self.out_tok[slot].copy_(toks)
             self.out_len[slot].copy_(lens)
             self.host_tok[slot].copy_(self.out_tok[slot], non_blocking=True)
@@ -145,9 +164,9 @@ class CaptionPipeline:
             self.ev_done[slot].record()
         self._submitted += 1
 
-    def _best_tokens(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        st = self.state
-        best = self.order[:, 0].long()
+    def _best_tokens(self, lane: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        st = self.states[lane]
+        best = self.order[lane][:, 0].long()
         bidx = torch.arange(self.B, device=best.device)
         toks = st.tokens[bidx, best]                                       # [B, T]
         lens = st.n_elem.view(self.B, self.k)[bidx, best]
@@ -157,12 +176,15 @@ class CaptionPipeline:
     def outstanding(self) -> int:
         return self._submitted - self._collected
 
+    def full(self) -> bool:
+        return self.outstanding() >= self.R
+
     def collect_device(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """Device tensors (int32 [B,T] EOS-padded tokens, int32 [B] lengths) of the oldest outstanding
         batch, ordered after its decode on the CURRENT stream (for a following collective)."""
         if self._collected >= self._submitted:
             raise RuntimeError("nothing outstanding")
-        slot = self._collected & 1
+        slot = self._collected % self.R
         torch.cuda.current_stream().wait_event(self.ev_done[slot])
         self._collected += 1
         return self.out_tok[slot], self.out_len[slot]
@@ -171,7 +193,7 @@ class CaptionPipeline:
         """Captions (token-id lists) of the oldest outstanding batch; blocks until it is decoded."""
         if self._collected >= self._submitted:
             raise RuntimeError("nothing outstanding")
-        slot = self._collected & 1
+        slot = self._collected % self.R
         self.ev_done[slot].synchronize()
         self._collected += 1
         toks, lens = self.host_tok[slot], self.host_len[slot]
@@ -179,6 +201,8 @@ class CaptionPipeline:
 
     def __call__(self, images: torch.Tensor) -> List[List[int]]:
         self.submit(images)
+        while self.outstanding() > 1:
+            self.collect()
         return self.collect()
 
 

@@ -284,6 +284,9 @@ def test_pipeline_matches_reference_best_caption(variant, graphs, poll):
     pipe = CaptionPipeline(m, 3, 3, 12, TSOS, TEOS, use_graphs=graphs, done_poll=poll)
     pipe.submit(img)
     pipe.submit(img.flip(0).contiguous())
+    pipe.submit(img)                                   # three outstanding: encode + two decode lanes
+    assert pipe.full()
     assert pipe.collect() == want
     assert pipe.collect() == want[::-1]
+    assert pipe.collect() == want
     assert pipe(img) == want

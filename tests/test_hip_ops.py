@@ -282,3 +282,21 @@ def test_dynexp_step_matches_full_recompute(ops):
                         *caches, qk, anc, valid, pos, y, d, y, d, scratch, N, T, d, E)
         got[:, step] = y.cpu()
     assert_close(got, want, 5e-5, "dynexp_step")
+
+
+@pytest.mark.parametrize("cfg", list(range(12)))
+def test_gemm_bf16_every_tile_config(ops, cfg):
+    """Each tile / pipeline-depth / BK instantiation against fp64 on ragged shapes (M, N not multiples
+    of any tile) with every epilogue feature on."""
+    from on_device_image_captioning_amd import _hip
+    lib = _hip.load()
+    try:
+        lib.odic_gemm_bf16_force_config(cfg)
+        for (M, N, K) in ((300, 328, 192), (517, 260, 320)):
+            A, Wt = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=0.05).bfloat16()
+            b, r = rnd(N, seed=3), rnd(M, N, seed=4)
+            want = torch.relu(0.5 * (A.double() @ Wt.double().T) + b.double()) + r.double()
+            got = ops.gemm(dev(A), dev(Wt), dev(b), dev(r), act=2, alpha=0.5, out_dtype=torch.float32)
+            assert_close(got, want, 2e-4, f"cfg{cfg} {M}x{N}x{K}")
+    finally:
+        lib.odic_gemm_bf16_force_config(-1)

@@ -10,6 +10,7 @@ import torch
 from on_device_image_captioning_amd import _hip, ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+CFGS = [int(c) for c in os.environ.get('ODIC_CFGS', '0,1,2,7,8,9,10,11').split(',')]
 lib = _hip.load()
 shapes = []
 for s, C in enumerate((192, 384, 768, 1536)):
@@ -18,7 +19,7 @@ for s, C in enumerate((192, 384, 768, 1536)):
     if s < 3:
         shapes.append((M // 4, 2 * C, 4 * C, "merge"))
 torch.manual_seed(0)
-print(f"{'shape':>26s} {'kind':>9s} | " + " | ".join(f"cfg{c}: us / TF/s" for c in range(3)))
+print(f"{'shape':>26s} {'kind':>9s} | " + " | ".join(f"cfg{c:<2d} us / TF/s" for c in CFGS))
 for M, N, K, kind in shapes:
     A = torch.randn(M, K, device="cuda").bfloat16()
     W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
@@ -28,7 +29,7 @@ for M, N, K, kind in shapes:
     out = torch.empty(M, N, device="cuda", dtype=odt)
     act = ops.ACT_GELU if "gelu" in kind else ops.ACT_NONE
     cells = []
-    for cfg in range(3):
+    for cfg in CFGS:
         lib.odic_gemm_bf16_force_config(cfg)
         for _ in range(3):
             ops.gemm(A, W, bias, res, out=out, act=act)
