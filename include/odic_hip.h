@@ -40,7 +40,7 @@ extern "C" {
 #define ODIC_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ODIC_ABI_VERSION 2
+#define ODIC_ABI_VERSION 3
 int odic_abi_version(void);
 
 /* Human-readable build string ("gfx950 hipcc ..."), static storage. */
@@ -70,6 +70,11 @@ typedef struct odic_gemm_args {
   int32_t in_dtype;   /* dtype of A and W */
   int32_t out_dtype;  /* dtype of out */
   int32_t tile_cfg;   /* bf16 only: tile configuration 0..11 (see csrc/gemm_bf16.hip), -1 = built-in choice */
+  /* Optional fused LayerNorm of the A operand (fp32 skinny-M path only: M <= 192, K % 16 == 0):
+   * A is then the un-normalised fp32 rows and the product is LayerNorm(A; ln_gamma, ln_beta, ln_eps)·Wᵀ.
+   * Replaces the separate norm_1/2/3 + dec_reduce_norm launches of the decoder step
+   * (layers.py:225,228,232; End_ExpansionNet_v2.py:135).  NULL = plain GEMM. */
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
 } odic_gemm_args;
 int odic_gemm(const odic_gemm_args* args, void* stream);
 

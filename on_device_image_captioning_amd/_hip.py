@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libodic_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _ERR = {-1: "ODIC_EINVAL (bad shape / alignment / enum)", -2: "ODIC_ENULL (required pointer is NULL)",
         -3: "ODIC_EUNSUPPORTED"}
@@ -29,7 +29,8 @@ class GemmArgs(C.Structure):
                 ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideBias", C.c_int64),
                 ("strideR", C.c_int64), ("strideC", C.c_int64),
                 ("alpha", C.c_float), ("act", C.c_int32), ("bias_axis", C.c_int32),
-                ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile_cfg", C.c_int32)]
+                ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile_cfg", C.c_int32),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float)]
 
 
 class BeamState(C.Structure):

@@ -22,6 +22,7 @@ struct Params {
   long lda, ldw, ldr, ldc;
   long strideA, strideW, strideBias, strideR, strideC;
   float alpha; int act; int bias_axis; int vec_ok;
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
 };
 
 __device__ __forceinline__ float4 load4(const float* base, long ld, int row, int nrows, int k, int K,
@@ -131,9 +132,9 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(Params p) {
 // K-order inside an MFMA is permuted (slot (kq, s) ↔ k = k0 + 4·kq + s) identically on both
 // operands, which only changes the summation order.
 // ---------------------------------------------------------------------------------------------
-template <int MT, typename OutT>
+template <int MT, bool LN, typename OutT>
 __global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int kslice) {
-  extern __shared__ float red[];                   // [nwaves][MT][4][64]
+  extern __shared__ float red[];                   // [nwaves][MT][4][64]  (+ [2][MT*16] row moments if LN)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int n0 = blockIdx.x * 16;
   const long bz = blockIdx.z;
@@ -145,6 +146,47 @@ __global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int ksl
   f32x4_t acc[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fused LayerNorm of A: every block recomputes the (tiny, L2-resident) row moments — wave w owns rows
+  // w, w+nwaves, ...; two-pass mean / centred variance with the row held in registers.
+  float* ln_mean = red + nwaves * MT * 256;
+  float* ln_rstd = ln_mean + MT * 16;
+  if constexpr (LN) {
+    // one 16-lane group per row (blockDim/16 rows per pass), the row slice held in registers
+    const int grp = tid >> 4, gl = tid & 15, ngrp = blockDim.x >> 4;
+    for (int r0 = 0; r0 < p.M; r0 += ngrp) {
+      const int r = r0 + grp;
+      const float* xr = A + (long)min(r, p.M - 1) * p.lda;
+      float4 v[16];                                  // K <= 1024: 16 lanes x 16 float4
+      float sm = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int c = (gl + 16 * t) * 4;
+        v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < p.K) { v[t] = *(const float4*)(xr + c); sm += (v[t].x + v[t].y) + (v[t].z + v[t].w); }
+      }
+      sm += __shfl_xor(sm, 8, 64); sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 1, 64);
+      const float mean = sm / (float)p.K;
+      float q = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int c = (gl + 16 * t) * 4;
+        if (c < p.K) {
+          const float a0 = v[t].x - mean, a1 = v[t].y - mean, a2 = v[t].z - mean, a3 = v[t].w - mean;
+          q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+      }
+      q += __shfl_xor(q, 8, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 1, 64);
+      if (gl == 0 && r < p.M) { ln_mean[r] = mean; ln_rstd[r] = rsqrtf(q / (float)p.K + p.ln_eps); }
+    }
+    __syncthreads();
+  }
+  float mu[MT], rs[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    mu[i] = 0.f; rs[i] = 1.f;
+    if constexpr (LN) { const int m = min(i * 16 + fr, p.M - 1); mu[i] = ln_mean[m]; rs[i] = ln_rstd[m]; }
+  }
 
   const bool wn_ok = (n0 + fr) < p.N;
   const float* wrow = W + (long)min(n0 + fr, p.N - 1) * p.ldw + 4 * fq;
@@ -171,8 +213,17 @@ __global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int ksl
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       if (k + 16 * u >= k_end || !wn_ok) w4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 g4, b4;
+      if constexpr (LN) {
+        const int kk = min(k + 16 * u, p.K - 16) + 4 * fq;
+        g4 = *(const float4*)(p.ln_gamma + kk); b4 = *(const float4*)(p.ln_beta + kk);
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
+        if constexpr (LN) {
+          a4[u][i].x = (a4[u][i].x - mu[i]) * rs[i] * g4.x + b4.x; a4[u][i].y = (a4[u][i].y - mu[i]) * rs[i] * g4.y + b4.y;
+          a4[u][i].z = (a4[u][i].z - mu[i]) * rs[i] * g4.z + b4.z; a4[u][i].w = (a4[u][i].w - mu[i]) * rs[i] * g4.w + b4.w;
+        }
         if (!am_ok[i]) a4[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][i].x, w4[u].x, acc[i], 0, 0, 0);
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][i].y, w4[u].y, acc[i], 0, 0, 0);
@@ -214,11 +265,15 @@ static void launch_skinny(const Params& p, int out_dtype, int batch, hipStream_t
   if (nw < 1) nw = 1;
   int kslice = ((p.K + nw - 1) / nw + 15) / 16 * 16;
   dim3 grid((p.N + 15) / 16, 1, batch), block(64 * nw);
-  const size_t shmem = (size_t)nw * MT * 256 * sizeof(float);
-  if (out_dtype == ODIC_BF16)
-    hipLaunchKernelGGL((gemm_f32_skinny_kernel<MT, bf16_raw>), grid, block, shmem, stream, p, kslice);
-  else
-    hipLaunchKernelGGL((gemm_f32_skinny_kernel<MT, float>), grid, block, shmem, stream, p, kslice);
+  const size_t shmem = (size_t)(nw * MT * 256 + 2 * MT * 16) * sizeof(float);
+  const bool ln = p.ln_gamma != nullptr;
+  if (out_dtype == ODIC_BF16) {
+    if (ln) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MT, true, bf16_raw>), grid, block, shmem, stream, p, kslice);
+    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<MT, false, bf16_raw>), grid, block, shmem, stream, p, kslice);
+  } else {
+    if (ln) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MT, true, float>), grid, block, shmem, stream, p, kslice);
+    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<MT, false, float>), grid, block, shmem, stream, p, kslice);
+  }
 }
 
 }  // namespace
@@ -231,9 +286,13 @@ int odic_gemm_f32_launch(const odic_gemm_args* a, hipStream_t stream) {
   p.strideA = a->strideA; p.strideW = a->strideW; p.strideBias = a->strideBias;
   p.strideR = a->strideR; p.strideC = a->strideC;
   p.alpha = a->alpha; p.act = a->act; p.bias_axis = a->bias_axis;
+  p.ln_gamma = a->ln_gamma; p.ln_beta = a->ln_beta; p.ln_eps = a->ln_eps;
   p.vec_ok = (a->lda % 4 == 0) && (a->ldw % 4 == 0) && (a->strideA % 4 == 0) && (a->strideW % 4 == 0) &&
              (((uintptr_t)a->A & 15) == 0) && (((uintptr_t)a->W & 15) == 0);
-  if (p.vec_ok && a->M <= 192 && a->K % 16 == 0 && a->N >= 64) {
+  const bool want_ln = a->ln_gamma != nullptr;
+  if (want_ln && (!a->ln_beta || !(p.vec_ok && a->M <= 192 && a->K % 16 == 0 && a->K <= 1024 && a->batch == 1)))
+    return ODIC_EUNSUPPORTED;
+  if (p.vec_ok && a->M <= 192 && a->K % 16 == 0 && (a->N >= 64 || want_ln)) {
     const int mt = (a->M + 15) / 16;
     if (mt <= 1) launch_skinny<1>(p, a->out_dtype, a->batch, stream);
     else if (mt <= 2) launch_skinny<2>(p, a->out_dtype, a->batch, stream);

@@ -134,10 +134,11 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
          M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None,
          lda: Optional[int] = None, ldw: Optional[int] = None, ldr: Optional[int] = None,
          ldc: Optional[int] = None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideBias: int = 0,
-         strideR: int = 0, strideC: int = 0) -> torch.Tensor:
+         strideR: int = 0, strideC: int = 0, ln: Optional[tuple] = None) -> torch.Tensor:
     """out = act(alpha·A·Wᵀ + bias) + residual.  With no explicit dims, A is [..., K] (flattened to
     [M,K]) and W is [N,K], both contiguous.  Explicit dims / leading dimensions / batch strides allow
-    strided sub-matrices (elements)."""
+    strided sub-matrices (elements).  ln = (gamma, beta, eps): LayerNorm fused on the rows of A (fp32
+    skinny-M path only)."""
     _need_cuda(A, W, bias, residual, out)
     if A.dtype != W.dtype:
         raise RuntimeError("A and W must share a dtype")
@@ -165,7 +166,8 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
         raise RuntimeError("residual must be fp32")
     a = _hip.GemmArgs(_p(A), _p(W), _p(bias), _p(residual), _p(out), M, N, K, lda, ldw, ldr or 0, ldc, batch,
                       strideA, strideW, strideBias, strideR, strideC, alpha, act, bias_axis,
-                      dtype_code(A.dtype), dtype_code(out.dtype), -1)
+                      dtype_code(A.dtype), dtype_code(out.dtype), -1,
+                      _p(ln[0]) if ln else None, _p(ln[1]) if ln else None, float(ln[2]) if ln else 0.0)
     if A.dtype == torch.bfloat16:
         key = (M, N, K, batch, out.dtype, act, residual is not None)
         cfg = _TILE_CHOICE.get(key)

@@ -79,6 +79,20 @@ def test_gemm_f32_row_bias_strided_batched(ops):
     assert torch.all(got[:, :, N:] == 7.0), "padding columns must stay untouched"
 
 
+def test_gemm_f32_fused_layernorm(ops):
+    # LayerNorm(A)·Wᵀ with A a strided slice of a wider buffer (the decoder's residual-stream layout)
+    M, N, K, lda = 48, 200, 512, 1536
+    buf, Wt, b = rnd(M, lda, seed=1, scale=2.0) + 0.3, rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    g, be = 1 + 0.1 * rnd(K, seed=4), 0.1 * rnd(K, seed=5)
+    A = buf[:, 512:1024]
+    want = torch.nn.functional.layer_norm(A.double(), (K,), g.double(), be.double(), 1e-5) @ Wt.double().T + b.double()
+    dbuf = dev(buf)
+    got = ops.gemm(dbuf[:, 512:], dev(Wt), dev(b), M=M, N=N, K=K, lda=lda, ldw=K, ldc=N, ln=(dev(g), dev(be), 1e-5))
+    assert_close(got, want, 3e-5, "fused LN gemm")
+    with pytest.raises(RuntimeError):          # not available outside the skinny fp32 path
+        ops.gemm(dev(rnd(400, 64, seed=1)), dev(rnd(64, 64, seed=2)), ln=(dev(rnd(64)), dev(rnd(64)), 1e-5))
+
+
 # ------------------------------------------------------------------------------------------ GEMM bf16
 def test_gemm_bf16_identity_asymmetric(ops):
     # A = I, asymmetric small-integer W: out must equal Wᵀ exactly (catches any fragment / C-layout swap)

@@ -35,7 +35,7 @@ def enc():
 
 
 def dec():
-    with torch.cuda.stream(pipe.s_dec):
+    with torch.cuda.stream(pipe.s_dec[0]):
         pipe._reset(0)
         for _ in range(pipe.steps):
             pipe.g_step[0].replay()
