@@ -29,7 +29,7 @@ constexpr int HD = 32;        // head dim of every Swin-L stage
 constexpr int MAXN = 144;     // ws*ws upper bound
 
 struct WinParams {
-  const void* qkv; const float* table; void* out;
+  const void* qkv; const float* table; const float* bias_dense; void* out;
   int B, res, C, heads, ws, shift, nwin_side;
   float scale;
 };
@@ -289,17 +289,166 @@ __global__ __launch_bounds__(192, 2) void window_attention_bf16_kernel(WinParams
   }
 }
 
+
+// =================================================================================================
+// bf16 MFMA kernel, v2 (used when the caller supplies the dense bias):
+//   * K and V are gathered straight into LDS by LDS-DMA (global_load_lds_dwordx4: per-lane source
+//     address = the window's token row, lane-linear destination = row-major [144][32]); no VGPR
+//     round trip and no transposing stores: V is consumed through ds_read_b64_tr_b16.
+//   * one 16-query tile at a time per wave: 36 score registers instead of 108 → 4+ blocks per CU.
+//   * softmax in base 2: scores = acc·(scale·log2e) + bias_dense (pre-multiplied by log2e on the
+//     host, already gathered through relative_position_index) → v_exp_f32 directly, 5 VALU per score.
+//   * the SW-MSA mask costs nothing on interior windows (wave-uniform branch); edge windows compare
+//     4 packed region ids per LDS word.
+// =================================================================================================
+typedef __attribute__((ext_vector_type(4))) short v4s_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__global__ __launch_bounds__(192, 4) void window_attention_bf16_v2_kernel(WinParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_raw Ks[MAXN][HD];        // 9216 B
+  __shared__ __attribute__((aligned(16))) bf16_raw Vs[MAXN + 16][HD];   // 10240 B (rows 144..159 zero)
+  __shared__ int rows[MAXN];
+  __shared__ __attribute__((aligned(4))) unsigned char rids[MAXN];
+
+  const int head = blockIdx.y;
+  const int win = blockIdx.x;
+  const int wpi = p.nwin_side * p.nwin_side;
+  const int b = win / wpi, wrem = win - b * wpi;
+  const int wy = wrem / p.nwin_side, wx = wrem - wy * p.nwin_side;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_raw* qkv = (const bf16_raw*)p.qkv;
+  const long ld = 3 * p.C;
+  const bool masked = p.shift > 0 && (wy == p.nwin_side - 1 || wx == p.nwin_side - 1);
+
+  if (tid < MAXN) {
+    long r; int rid;
+    slot_to_token(p, b, wy, wx, tid, r, rid);
+    rows[tid] = (int)r; rids[tid] = (unsigned char)rid;
+  }
+  if (tid < 128) ((unsigned long long*)&Vs[MAXN][0])[tid] = 0ull;       // 16 x 64 B of padding keys
+  __syncthreads();
+
+  // ---- LDS-DMA gather: instruction i covers window slots 16i .. 16i+15 (16 rows x 64 B = 1 KiB)
+  {
+    const int r_in = lane >> 2, ch = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int blk = wave * 3 + i;                                       // 0..8
+      const bf16_raw* src = qkv + (long)rows[blk * 16 + r_in] * ld + head * HD + ch * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + p.C), (lptr_t)((char*)&Ks[0][0] + blk * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + 2 * p.C), (lptr_t)((char*)&Vs[0][0] + blk * 1024), 16, 0, 0);
+    }
+  }
+  // ---- Q fragments (B operand of Sᵀ = K·Qᵀ): Q[query = fr][d = 8·fq ..]
+  const int fr = lane & 15, fq = lane >> 4;
+  bf16x8_t qf[3];
+#pragma unroll
+  for (int qt = 0; qt < 3; ++qt)
+    qf[qt] = *(const bf16x8_t*)(qkv + (long)rows[(wave * 3 + qt) * 16 + fr] * ld + head * HD + fq * 8);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float scale2 = p.scale * 1.4426950408889634f;
+  bf16_raw* out = (bf16_raw*)p.out;
+  // transposed-read addresses of V: lane (fr = 4q+p) of 16-lane group fq supplies row r0+q, cols 4p..4p+3
+  const char* vbase = (const char*)&Vs[0][0] + ((4 * fq + (fr >> 2)) * HD + 4 * (fr & 3)) * 2;
+
+#pragma unroll 1
+  for (int qt = 0; qt < 3; ++qt) {
+    const int qn = (wave * 3 + qt) * 16 + fr;
+    const float* brow = p.bias_dense + ((long)head * MAXN + qn) * MAXN + fq * 4;
+    float4 bias[9];
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) bias[kt] = *(const float4*)(brow + kt * 16);
+
+    f32x4_t sc[9];
+    const bf16x8_t q = qt == 0 ? qf[0] : (qt == 1 ? qf[1] : qf[2]);
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+      const bf16x8_t kf = *(const bf16x8_t*)&Ks[kt * 16 + fr][fq * 8];
+      sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, q, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+      sc[kt][0] = fmaf(sc[kt][0], scale2, bias[kt].x); sc[kt][1] = fmaf(sc[kt][1], scale2, bias[kt].y);
+      sc[kt][2] = fmaf(sc[kt][2], scale2, bias[kt].z); sc[kt][3] = fmaf(sc[kt][3], scale2, bias[kt].w);
+    }
+    if (masked) {
+      const unsigned my = rids[qn];
+#pragma unroll
+      for (int kt = 0; kt < 9; ++kt) {
+        const unsigned kr = *(const unsigned*)&rids[kt * 16 + fq * 4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (((kr >> (8 * j)) & 0xff) != my) sc[kt][j] -= 144.26950408889634f;          // -100 · log2e
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) m = fmaxf(fmaxf(m, fmaxf(sc[kt][0], sc[kt][1])), fmaxf(sc[kt][2], sc[kt][3]));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float e = __builtin_amdgcn_exp2f(sc[kt][j] - m);
+        sc[kt][j] = e;
+        l += e;
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv_l = 1.0f / l;
+
+    // Oᵀ = Vᵀ·Pᵀ : K-slot (fq, e) of step s ↔ key 32s + 16(e>>2) + 4fq + (e&3) on both operands
+    f32x4_t oacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+      bf16x8_t pf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pf[e] = (short)f32_to_bf16(sc[2 * s5][e]);
+      if (s5 < 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf[4 + e] = (short)f32_to_bf16(sc[2 * s5 + 1][e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf[4 + e] = 0;
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s_t*)(vbase + (32 * s5) * HD * 2 + nt * 32));
+        const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s_t*)(vbase + (32 * s5 + 16) * HD * 2 + nt * 32));
+        const bf16x8_t vf = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        oacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[nt], 0, 0, 0);
+      }
+    }
+    bf16_raw* dst = out + (long)rows[qn] * p.C + head * HD + fq * 4;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      ushort4 pk;
+      pk.x = f32_to_bf16(oacc[nt][0] * inv_l); pk.y = f32_to_bf16(oacc[nt][1] * inv_l);
+      pk.z = f32_to_bf16(oacc[nt][2] * inv_l); pk.w = f32_to_bf16(oacc[nt][3] * inv_l);
+      *(ushort4*)(dst + nt * 16) = pk;
+    }
+  }
+}
+
 }  // namespace
 
-extern "C" int odic_window_attention(const void* qkv, const float* bias_table, void* out, int32_t B,
-                                     int32_t res, int32_t C, int32_t heads, int32_t ws, int32_t shift,
-                                     float scale, int32_t dtype, void* stream) {
+extern "C" int odic_window_attention(const void* qkv, const float* bias_table, const float* bias_dense_log2,
+                                     void* out, int32_t B, int32_t res, int32_t C, int32_t heads, int32_t ws,
+                                     int32_t shift, float scale, int32_t dtype, void* stream) {
   if (!qkv || !bias_table || !out) return ODIC_ENULL;
   if (B <= 0 || ws <= 0 || ws * ws > MAXN || res % ws || heads * HD != C || shift < 0 || shift >= ws)
     return ODIC_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return ODIC_EINVAL;
   WinParams p;
-  p.qkv = qkv; p.table = bias_table; p.out = out; p.B = B; p.res = res; p.C = C; p.heads = heads;
+  p.qkv = qkv; p.table = bias_table; p.bias_dense = bias_dense_log2; p.out = out; p.B = B; p.res = res; p.C = C; p.heads = heads;
   p.ws = ws; p.shift = shift; p.nwin_side = res / ws; p.scale = scale;
   dim3 grid(B * p.nwin_side * p.nwin_side, heads), block(192);
   hipStream_t s = (hipStream_t)stream;
@@ -307,7 +456,10 @@ extern "C" int odic_window_attention(const void* qkv, const float* bias_table, v
     hipLaunchKernelGGL(window_attention_f32_kernel, grid, block, 0, s, p);
   } else if (dtype == ODIC_BF16) {
     if (ws != 12) return ODIC_EUNSUPPORTED;      // MFMA tiling is specialised for N = 144
-    hipLaunchKernelGGL(window_attention_bf16_kernel, grid, block, 0, s, p);
+    if (bias_dense_log2 && (long)B * res * res < 2147483647L && !(((uintptr_t)bias_dense_log2) & 15))
+      hipLaunchKernelGGL(window_attention_bf16_v2_kernel, grid, block, 0, s, p);
+    else
+      hipLaunchKernelGGL(window_attention_bf16_kernel, grid, block, 0, s, p);
   } else {
     return ODIC_EINVAL;
   }

@@ -52,7 +52,7 @@ def test_argument_validation_needs_no_gpu(lib):
     a.M, a.N, a.K, a.batch = 0, 4, 4, 1
     assert lib.odic_gemm(ctypes.byref(a), None) == -1
     assert lib.odic_layernorm(None, 0, None, None, None, 1, 4, 1e-5, 0, None) == -2
-    assert lib.odic_window_attention(16, 16, 16, 1, 12, 100, 3, 12, 0, 1.0, 1, None) == -1   # heads*32 != C
+    assert lib.odic_window_attention(16, 16, None, 16, 1, 12, 100, 3, 12, 0, 1.0, 1, None) == -1   # heads*32 != C
 
 
 def test_product_path_has_no_cpu_fallback():
