@@ -187,3 +187,15 @@ def test_tokens2description_strings():
     for toks, want in helper["tokens2description"]:
         assert tokens2description(toks, i2w, SOS, EOS) == want
         assert R.tokens2description(toks, i2w, SOS, EOS) == want
+
+
+def test_cider_d_matches_reference_scorer():
+    """F1: own CIDEr-D scorer vs scores recorded from the reference's eval/cider (oracle/make_golden_cider.py)."""
+    from on_device_image_captioning_amd.cider import CiderD
+    cases = json.load(open(os.path.join(GOLDEN, "cider.json")))
+    assert len(cases) == 4
+    for c in cases:
+        score, scores = CiderD().compute_score(c["gts"], c["res"])
+        assert abs(score - c["score"]) < 1e-9
+        np.testing.assert_allclose(scores, c["scores"], atol=1e-9)
+    assert max(c["score"] for c in cases) > 1.0       # non-degenerate fixtures
