@@ -311,9 +311,14 @@ __global__ __launch_bounds__(192, 4) void window_attention_bf16_v2_kernel(WinPar
   __shared__ int rows[MAXN];
   __shared__ __attribute__((aligned(4))) unsigned char rids[MAXN];
 
-  const int head = blockIdx.y;
-  const int win = blockIdx.x;
+  // Block → (window, head): blocks b, b+8, ... share an XCD and its L2.  Each XCD walks its windows with
+  // the HEAD index fastest, so the 64-byte q/k/v segments of neighbouring heads — two per 128-byte
+  // line — are requested back-to-back from the same L2 and every HBM line is fetched once.
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int head = idx % p.heads;
+  const int win = (idx / p.heads) * 8 + xcd;
   const int wpi = p.nwin_side * p.nwin_side;
+  if (win >= p.B * wpi) return;
   const int b = win / wpi, wrem = win - b * wpi;
   const int wy = wrem / p.nwin_side, wx = wrem - wy * p.nwin_side;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -456,8 +461,10 @@ extern "C" int odic_window_attention(const void* qkv, const float* bias_table, c
     hipLaunchKernelGGL(window_attention_f32_kernel, grid, block, 0, s, p);
   } else if (dtype == ODIC_BF16) {
     if (ws != 12) return ODIC_EUNSUPPORTED;      // MFMA tiling is specialised for N = 144
-    if (bias_dense_log2 && (long)B * res * res < 2147483647L && !(((uintptr_t)bias_dense_log2) & 15))
-      hipLaunchKernelGGL(window_attention_bf16_v2_kernel, grid, block, 0, s, p);
+    if (bias_dense_log2 && (long)B * res * res < 2147483647L && !(((uintptr_t)bias_dense_log2) & 15)) {
+      const int nwin = B * p.nwin_side * p.nwin_side;
+      hipLaunchKernelGGL(window_attention_bf16_v2_kernel, dim3(((nwin + 7) / 8) * 8 * heads), block, 0, s, p);
+    }
     else
       hipLaunchKernelGGL(window_attention_bf16_kernel, grid, block, 0, s, p);
   } else {
