@@ -142,9 +142,12 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("ODIC_FORCE_DIST"))     # (forced: exercises RCCL with one rank)
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" is RCCL on ROCm
 
     from on_device_image_captioning_amd import weights as W
     from on_device_image_captioning_amd.pipeline import CaptionPipeline, gather_captions
@@ -156,7 +159,7 @@ def main():
 
     def finish_one():
         """Captions of the oldest outstanding batch on the host (N > 1: after the RCCL all_gather)."""
-        if world > 1:
+        if use_dist:
             toks, lens = pipe.collect_device()
             return gather_captions(toks, lens, a.batch * world)
         return pipe.collect()
@@ -174,16 +177,16 @@ def main():
         return caps
 
     run(a.warmup)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     caps = run(a.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -217,7 +220,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, g, a.cpu_runs, a.beam, a.max_len)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -221,22 +221,20 @@ def shard_indices(n_items: int, rank: int, world: int) -> Tuple[int, int, int]:
 def gather_captions(tokens: torch.Tensor, lengths: torch.Tensor, n_items: int, group=None
                     ) -> Optional[List[List[int]]]:
     """tokens int [per, T] / lengths int [per] of THIS rank's shard (rows beyond the shard padded) →
-    on every rank the full list of `n_items` captions in global order.  One all_gather each (RCCL
-    over xGMI on GPUs, gloo on CPU); payload = world·per·(T+1)·4 bytes, latency-bound."""
+    on every rank the full list of `n_items` captions in global order.  ONE all_gather (RCCL over
+    xGMI on GPUs, gloo on CPU); payload = world·per·(T+1)·4 bytes, latency-bound."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         toks, lens = tokens.cpu(), lengths.cpu()
         return [toks[i, :int(lens[i])].tolist() for i in range(min(n_items, toks.shape[0]))]
     world = dist.get_world_size(group)
-    t32 = tokens.to(torch.int32).contiguous()
-    l32 = lengths.to(torch.int32).contiguous()
-    parts_t = [torch.empty_like(t32) for _ in range(world)]
-    parts_l = [torch.empty_like(l32) for _ in range(world)]
-    dist.all_gather(parts_t, t32, group=group)
-    dist.all_gather(parts_l, l32, group=group)
-    all_t = torch.cat(parts_t, 0).cpu()
-    all_l = torch.cat(parts_l, 0).cpu()
-    return [all_t[i, :int(all_l[i])].tolist() for i in range(n_items)]
+    # one collective: lengths ride in an extra column of the token tensor
+    packed = torch.cat([tokens.to(torch.int32), lengths.to(torch.int32)[:, None]], dim=1).contiguous()
+    parts = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(parts, packed, group=group)
+    allp = torch.cat(parts, 0).cpu()
+    T = tokens.shape[1]
+    return [allp[i, :int(allp[i, T])].tolist() for i in range(n_items)]
 
 
 def caption_sharded(caption_batch, n_items: int, fetch, batch: int, T: int, eos_idx: int, device,
