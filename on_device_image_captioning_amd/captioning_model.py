@@ -128,8 +128,48 @@ class CaptioningModel(nn.Module):
 
     def get_batch_multiple_sampled_prediction(self, enc_input, enc_input_num_pads, num_outputs, sos_idx, eos_idx,
                                               max_seq_len):
-        raise NotImplementedError("mode='sampling' (SCST sampling, SURVEY §8(f) F3) is not part of the "
-                                  "accelerated inference path yet")
+        """mode='sampling' (legacy_models/captioning_model.py:59-109): `num_outputs` ancestral samples per
+        image.  Each step runs the incremental decoder, a device-side log-softmax and one
+        torch.multinomial draw per sequence (the draws use torch's device RNG, so individual samples are
+        not reproducible against the reference's CPU generator; what IS checkable — and tested — is that
+        every reported log-prob equals the teacher-forced log-prob of the returned sequence)."""
+        eng = self._captioner_engine()
+        dv = eng.device
+        mem = self.forward_enc(enc_input, enc_input_num_pads)
+        bs, S, _ = mem.shape
+        N = bs * num_outputs
+        V = eng.g.vocab_size
+        enc_len = self._enc_lens(bs, S, enc_input_num_pads)
+        st = eng.new_state(bs, num_outputs, max_seq_len + 1, eng.project_kv(mem), enc_len)
+        st.anc.copy_(torch.arange(N, dtype=torch.int32, device=dv)[:, None].expand(N, max_seq_len + 1))
+        st.next_tok.fill_(sos_idx)
+        st.row_valid.fill_(1)
+        logp = torch.empty(N, V, dtype=torch.float32, device=dv)
+        toks = torch.full((N, max_seq_len + 1), sos_idx, dtype=torch.int64, device=dv)
+        lps = torch.zeros(N, max_seq_len + 1, dtype=torch.float32, device=dv)
+        where_eos = torch.full((N,), max_seq_len, dtype=torch.int64, device=dv)
+        finished = torch.zeros(N, dtype=torch.bool, device=dv)
+        t = 0
+        while t < max_seq_len:
+            st.pos.fill_(t)
+            eng.step_logits(st)
+            ops.logsoftmax_topk(st.logits, V, logp, V, st.cand_val, st.cand_idx, N, V, 1)
+            nxt = torch.multinomial(torch.exp(logp), 1).squeeze(1)
+            toks[:, t + 1] = nxt
+            lps[:, t + 1] = logp.gather(1, nxt[:, None]).squeeze(1)
+            t += 1
+            hit = nxt == eos_idx
+            where_eos = torch.minimum(where_eos, torch.where(hit, torch.full_like(where_eos, t), where_eos))
+            finished |= hit
+            st.next_tok.copy_(nxt)
+            if t % _DONE_POLL == 0 and bool(finished.all()):
+                break
+        toks_h, eos_h = toks.cpu(), where_eos.cpu()
+        res = [[toks_h[i * num_outputs + j, :int(eos_h[i * num_outputs + j]) + 1].tolist()
+                for j in range(num_outputs)] for i in range(bs)]
+        ar = torch.arange(t + 1, device=dv)[None, :]
+        probs = lps[:, :t + 1].masked_fill(ar > where_eos[:, None], 0.0).reshape(bs, num_outputs, -1)
+        return res, probs
 
     # ------------------------------------------------------------------ search
     def beam_search(self, enc_input, enc_input_num_pads, sos_idx, eos_idx, beam_size=3, how_many_outputs=1,
@@ -137,14 +177,12 @@ class CaptioningModel(nn.Module):
         assert (how_many_outputs <= beam_size), "requested output per sequence must be lower than beam width"
         assert (sample_or_max == "max" or sample_or_max == "sample"), \
             "argument must be chosen between 'max' and 'sample'"
-        if sample_or_max == "sample":
-            raise NotImplementedError("sample_or_max='sample' (SURVEY §8(f) F3) is not accelerated yet")
         mem = self.forward_enc(enc_input, enc_input_num_pads)
         return self._search_from_memory(mem, enc_input_num_pads, sos_idx, eos_idx, beam_size, how_many_outputs,
-                                        max_seq_len)
+                                        max_seq_len, sample=(sample_or_max == "sample"))
 
     def _search_from_memory(self, mem, enc_input_num_pads, sos_idx, eos_idx, beam_size, how_many_outputs,
-                            max_seq_len) -> Tuple[List[List[List[int]]], torch.Tensor]:
+                            max_seq_len, sample: bool = False) -> Tuple[List[List[List[int]]], torch.Tensor]:
         eng = self._captioner_engine()
         dv = eng.device
         B, S, _ = mem.shape
@@ -155,8 +193,20 @@ class CaptioningModel(nn.Module):
         st = eng.new_state(B, k, T, eng.project_kv(mem), enc_len)
         st.tokens[:, :, 0] = sos_idx
         st.next_tok.fill_(sos_idx)
+        V = eng.g.vocab_size
+        logp = torch.empty(st.N, V, dtype=torch.float32, device=dv) if sample else None
         for t in range(steps):
-            eng.beam_step(st, eos_idx)
+            if sample:
+                # 'sample' variant (captioning_model.py:128-131,166-168): the k candidates of every beam are
+                # drawn without replacement from its distribution instead of being its top-k
+                eng.step_logits(st)
+                ops.logsoftmax_topk(st.logits, V, logp, V, st.cand_val, st.cand_idx, st.N, V, 1)
+                draw = torch.multinomial(torch.exp(logp), k, replacement=False)
+                st.cand_idx.copy_(draw.to(torch.int32))
+                st.cand_val.copy_(logp.gather(1, draw))
+                ops.beam_step(st.cand_val, st.cand_idx, st.beam_state, st.n_img, st.beams, st.T, eos_idx)
+            else:
+                eng.beam_step(st, eos_idx)
             if t >= 1 and (t + 1) % _DONE_POLL == 0 and t + 1 < steps and int(st.done.item()):
                 break
         order = torch.empty(B, k, dtype=torch.int32, device=dv)

@@ -35,7 +35,8 @@ class CaptionPipeline:
     the scheduling across batches is overlapped."""
 
     def __init__(self, model: CaptioningModel, batch: int, beam_size: int, max_seq_len: int, sos_idx: int,
-                 eos_idx: int, use_graphs: bool = True, done_poll: int = 0, decode_lanes: int = 2):
+                 eos_idx: int, use_graphs: bool = True, done_poll: int = 0, decode_lanes: int = 2,
+                 streams=None):
         """done_poll = 0: never look at the `done` flag (fixed work per batch — benchmark mode with
         weights that never emit EOS); n > 0: host checks every n steps and stops early."""
         self.model, self.B, self.k = model, batch, beam_size
@@ -59,8 +60,11 @@ class CaptionPipeline:
         self.states = [cap.new_state(batch, beam_size, self.T, self.kv[l], self.enc_len) for l in range(self.D)]
         self.order = [torch.empty(batch, beam_size, dtype=torch.int32, device=dv) for _ in range(self.D)]
         self.score = [torch.empty(batch, beam_size, dtype=torch.float32, device=dv) for _ in range(self.D)]
-        self.s_enc = torch.cuda.Stream(device=dv)
-        self.s_dec = [torch.cuda.Stream(device=dv) for _ in range(self.D)]
+        if streams is not None:                                    # (encode stream, [decode streams]) supplied by the caller
+            self.s_enc, self.s_dec = streams[0], list(streams[1])
+        else:
+            self.s_enc = torch.cuda.Stream(device=dv)
+            self.s_dec = [torch.cuda.Stream(device=dv) for _ in range(self.D)]
         self.ev_enc = torch.cuda.Event()
         self.ev_kv_taken = torch.cuda.Event()
         self.ev_kv_taken.record()

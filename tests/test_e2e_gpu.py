@@ -290,3 +290,37 @@ def test_pipeline_matches_reference_best_caption(variant, graphs, poll):
     assert pipe.collect() == want[::-1]
     assert pipe.collect() == want
     assert pipe(img) == want
+
+
+# ----------------------------------------------------------------------------------------- F3: sampling
+def test_sampling_mode_logprobs_are_teacher_forced_logprobs():
+    """mode='sampling' draws tokens with the device RNG (not reproducible against the reference's CPU
+    generator), but the log-prob it reports for every drawn token must be the model's log-prob of that
+    token given the prefix — checked against an independent teacher-forced pass of the CPU oracle."""
+    from oracle import expansionnet_ref as R
+    g = W.TINY
+    sd = cached_state_dict("TINY", "eos")
+    m = build_model("TINY", "eos")
+    img = W.synth_images(2, g)
+    torch.manual_seed(0)
+    toks, lps = m(enc_x=img.to(DEV), enc_x_num_pads=[0, 0], mode="sampling", how_many_outputs=3,
+                  sample_max_seq_len=10, sos_idx=TSOS, eos_idx=TEOS)
+    assert len(toks) == 2 and all(len(per) == 3 for per in toks)
+    mem = R.forward_enc(sd, g, img, [0, 0])
+    lens = set()
+    for b in range(2):
+        for j in range(3):
+            seq = toks[b][j]
+            lens.add(len(seq))
+            assert seq[0] == TSOS and TEOS not in seq[1:-1]
+            dec = torch.tensor([seq])
+            ref = R.decoder_forward(sd, g, mem[b:b + 1], [0], dec, [0], True)[0]
+            want = [0.0] + [float(ref[t, seq[t + 1]]) for t in range(len(seq) - 1)]
+            got = lps[b, j, :len(seq)].cpu().tolist()
+            np.testing.assert_allclose(got, want, atol=2e-3)
+            assert float(lps[b, j, len(seq):].abs().sum()) == 0.0
+    # sampled beam search runs and returns well-formed output
+    toks2, lps2 = m(enc_x=img.to(DEV), enc_x_num_pads=[0, 0], mode="beam_search", beam_size=3, how_many_outputs=2,
+                    beam_max_seq_len=8, sample_or_max="sample", sos_idx=TSOS, eos_idx=TEOS)
+    assert len(toks2) == 2 and all(len(per) == 2 and per[0][0] == TSOS for per in toks2)
+    assert lps2.shape[:2] == (2, 2)
