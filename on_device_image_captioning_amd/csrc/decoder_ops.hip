@@ -180,8 +180,9 @@ __global__ __launch_bounds__(512) void dynexp_scores_kernel(DynParams p) {
 // class vectors.  All loads of one j are independent (2·E in flight per thread), coalesced over c.
 template <int EE>
 __global__ __launch_bounds__(128) void dynexp_accum_kernel(DynParams p) {
-  __shared__ float w[4 * MAX_T * EE];
-  __shared__ int slot[MAX_T];
+  extern __shared__ float w[];             // 4 x [T][EE] weight tables + [T] slots — sized by T, not MAX_T
+  const int TS = p.T * EE;
+  int* slot = (int*)(w + 4 * TS);
   const int d = p.d, n = blockIdx.x, tid = threadIdx.x;
   const int c = blockIdx.y * 128 + tid;
   const int t = *p.pos;
@@ -190,14 +191,14 @@ __global__ __launch_bounds__(128) void dynexp_accum_kernel(DynParams p) {
   const float* scr = p.scratch + (long)n * dyn_scratch_stride(p.T, EE);
   const int used = (t + 1) * EE;
   for (int i = tid; i < used; i += 128) {
-    w[i] = scr[i]; w[MAX_T * EE + i] = scr[TE + i];
-    w[2 * MAX_T * EE + i] = scr[2 * TE + i]; w[3 * MAX_T * EE + i] = scr[3 * TE + i];
+    w[i] = scr[i]; w[TS + i] = scr[TE + i];
+    w[2 * TS + i] = scr[2 * TE + i]; w[3 * TS + i] = scr[3 * TE + i];
   }
   for (int j = tid; j <= t; j += 128) slot[j] = ((const int*)(scr + 4 * TE))[j];
   __syncthreads();
   if (c >= d) return;
-  const float* wfa = w; const float* wfb = w + MAX_T * EE;
-  const float* wba = w + 2 * MAX_T * EE; const float* wbb = w + 3 * MAX_T * EE;
+  const float* wfa = w; const float* wfb = w + TS;
+  const float* wba = w + 2 * TS; const float* wbb = w + 3 * TS;
   const float* lin = p.lin + (long)n * p.ldlin;
 
   float fa[EE], fb[EE];
@@ -536,11 +537,12 @@ extern "C" int odic_dynexp_step(const float* lin, int64_t ldlin, const float* qe
                        MAX_T * sizeof(int);
   hipLaunchKernelGGL(dynexp_scores_kernel, dim3(N), dim3(512), shmem, s, p);
   dim3 grid(N, (d + 127) / 128);
+  const size_t sh2 = (size_t)(4 * T * E) * sizeof(float) + (size_t)T * sizeof(int);
   switch (E) {
-    case 4: hipLaunchKernelGGL(dynexp_accum_kernel<4>, grid, dim3(128), 0, s, p); break;
-    case 8: hipLaunchKernelGGL(dynexp_accum_kernel<8>, grid, dim3(128), 0, s, p); break;
-    case 16: hipLaunchKernelGGL(dynexp_accum_kernel<16>, grid, dim3(128), 0, s, p); break;
-    default: hipLaunchKernelGGL(dynexp_accum_kernel<32>, grid, dim3(128), 0, s, p); break;
+    case 4: hipLaunchKernelGGL(dynexp_accum_kernel<4>, grid, dim3(128), sh2, s, p); break;
+    case 8: hipLaunchKernelGGL(dynexp_accum_kernel<8>, grid, dim3(128), sh2, s, p); break;
+    case 16: hipLaunchKernelGGL(dynexp_accum_kernel<16>, grid, dim3(128), sh2, s, p); break;
+    default: hipLaunchKernelGGL(dynexp_accum_kernel<32>, grid, dim3(128), sh2, s, p); break;
   }
   return odic_launch_status();
 }

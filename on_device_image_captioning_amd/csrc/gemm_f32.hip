@@ -15,6 +15,9 @@
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDP = BK + 1;
+#ifndef ODIC_SKINNY_LDS_KIB
+#define ODIC_SKINNY_LDS_KIB 12      // stay below the ~16 KiB a CU has left beside the encode stream's GEMM blocks (sweep: 6→1420, 9→1455, 15→1448, 48→1430 captions/s)
+#endif
 
 struct Params {
   const float* A; const float* W; const float* bias; const float* residual; void* out;
@@ -261,7 +264,7 @@ static void launch_skinny(const Params& p, int out_dtype, int batch, hipStream_t
   // waves: aim at K-slices of ~64, at most 16 waves, LDS for the reduction <= 48 KiB
   int nw = (p.K + 63) / 64;
   if (nw > 16) nw = 16;
-  while (nw > 1 && nw * MT > 48) --nw;
+  while (nw > 1 && nw * MT > ODIC_SKINNY_LDS_KIB) --nw;      // per-wave split-K slabs: nw·MT KiB of LDS
   if (nw < 1) nw = 1;
   int kslice = ((p.K + nw - 1) / nw + 15) / 16 * 16;
   dim3 grid((p.N + 15) / 16, 1, batch), block(64 * nw);
