@@ -50,6 +50,13 @@ template <int BK> __device__ __forceinline__ int swz(int chunk, int row) {
   else return chunk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3);
 }
 
+// LDS row r of the W tile holds tile-local output column wperm(r): inside each 32-row group the two
+// 16-row MFMA tiles interleave in runs of 4, so that MFMA slot 4·fq + j of tile h is column
+// 8·fq + 4·h + j and a lane's registers across the tile pair are 8 adjacent output columns.
+__device__ __forceinline__ int wperm(int r) {
+  return (r & ~31) + 8 * ((r & 15) >> 2) + 4 * ((r >> 4) & 1) + (r & 3);
+}
+
 template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK, typename OutT>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) {
   constexpr int NW = NWM * NWN;
@@ -61,6 +68,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
   constexpr int A_INSTR = BM / RPI / NW, W_INSTR = BN / RPI / NW;  // 1-KiB DMA instructions per wave
   static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "tile rows must split evenly over the waves");
   constexpr int G = A_INSTR + W_INSTR;                                 // LDS-DMA instructions per wave per K-tile
+  static_assert(NI % 2 == 0, "the epilogue pairs MFMA column tiles");
   constexpr int D = NSTAGE - 1;                                        // prefetch distance in K-tiles
   extern __shared__ __attribute__((aligned(16))) char lds[];          // stage0 {A,W} | stage1 {A,W}
 
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
 #pragma unroll
   for (int i = 0; i < W_INSTR; ++i) {
     const int row = (i * NW + wave) * RPI + srow;
-    w_src[i] = W + (long)min(n0 + row, p.N - 1) * p.ldw + schunk * 8;
+    w_src[i] = W + (long)min(n0 + wperm(row), p.N - 1) * p.ldw + schunk * 8;
   }
 
   auto stage = [&](int buf, int kt) {
@@ -155,54 +163,57 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
     }
   }
   // ---- epilogue.  With the operands swapped the 16x16 accumulator is Cᵀ: lane (frow, fq) register j
-  //      holds C[m = frow][n = 4·fq + j]  →  one 4-wide row vector per (mi, ni).
+  //      holds output row frow, W-slot 4·fq + j.  The W rows were staged permuted (wperm above), so
+  //      the slot pair (2q, 2q+1) of a lane covers 8 CONSECUTIVE output columns 32q + 8·fq .. +7:
+  //      one 16-byte bf16 store (or two adjacent float4) per lane, 64/128 contiguous bytes per row.
   const float* bias = p.bias ? p.bias + bz * p.strideBias : nullptr;
   const float* resid = p.residual ? p.residual + bz * p.strideR : nullptr;
   OutT* out = (OutT*)p.out + bz * p.strideC;
-  const bool ld_ok = ((p.ldc & 3) == 0) && (!resid || (p.ldr & 3) == 0);
-  float4 bcol[NI];
+  const bool ld_ok = ((p.ldc & 7) == 0) && (!resid || (p.ldr & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int col = n0 + (wn * NI + ni) * 16 + fq * 4;
-    bcol[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias && !p.bias_axis) {
-      bcol[ni].x = col + 0 < p.N ? bias[col + 0] : 0.f; bcol[ni].y = col + 1 < p.N ? bias[col + 1] : 0.f;
-      bcol[ni].z = col + 2 < p.N ? bias[col + 2] : 0.f; bcol[ni].w = col + 3 < p.N ? bias[col + 3] : 0.f;
-    }
-  }
+  for (int nq = 0; nq < NI / 2; ++nq) {
+    const int col = n0 + wn * NI * 16 + nq * 32 + fq * 8;
+    if (col >= p.N) continue;
+    float bc[8];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int row = m0 + (wm * MI + mi) * 16 + frow;
-    if (row >= p.M) continue;
-    const float brow = (bias && p.bias_axis) ? bias[row] : 0.f;
+    for (int e = 0; e < 8; ++e) bc[e] = (bias && !p.bias_axis && col + e < p.N) ? bias[col + e] : 0.f;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int col = n0 + (wn * NI + ni) * 16 + fq * 4;
-      if (col >= p.N) continue;
-      float4 v;
-      v.x = apply_act<true>(acc[mi][ni][0] * p.alpha + bcol[ni].x + brow, p.act);
-      v.y = apply_act<true>(acc[mi][ni][1] * p.alpha + bcol[ni].y + brow, p.act);
-      v.z = apply_act<true>(acc[mi][ni][2] * p.alpha + bcol[ni].z + brow, p.act);
-      v.w = apply_act<true>(acc[mi][ni][3] * p.alpha + bcol[ni].w + brow, p.act);
-      if (ld_ok && col + 3 < p.N) {
+    for (int mi = 0; mi < MI; ++mi) {
+      const int row = m0 + (wm * MI + mi) * 16 + frow;
+      if (row >= p.M) continue;
+      const float brow = (bias && p.bias_axis) ? bias[row] : 0.f;
+      f32x4_t v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4_t pre = acc[mi][2 * nq + h] * p.alpha + f32x4_t{bc[4 * h], bc[4 * h + 1], bc[4 * h + 2], bc[4 * h + 3]} + brow;
+        if (p.act == ODIC_ACT_GELU) {
+          pre = gelu_poly4(pre);
+        } else if (p.act != ODIC_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pre[e] = apply_act<true>(pre[e], p.act);
+        }
+        v[h] = pre;
+      }
+      if (ld_ok && col + 7 < p.N) {
         if (resid) {
-          const float4 rr = *(const float4*)(resid + (long)row * p.ldr + col);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          const f32x4_t* rp = (const f32x4_t*)(resid + (long)row * p.ldr + col);
+          v[0] += rp[0]; v[1] += rp[1];
         }
         OutT* dst = out + (long)row * p.ldc + col;
         if constexpr (sizeof(OutT) == 4) {
-          *(float4*)dst = v;
+          ((f32x4_t*)dst)[0] = v[0]; ((f32x4_t*)dst)[1] = v[1];
         } else {
-          ushort4 pk;
-          pk.x = f32_to_bf16(v.x); pk.y = f32_to_bf16(v.y); pk.z = f32_to_bf16(v.z); pk.w = f32_to_bf16(v.w);
-          *(ushort4*)dst = pk;
+          bf16x8_t pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { pk[e] = (short)f32_to_bf16(v[0][e]); pk[4 + e] = (short)f32_to_bf16(v[1][e]); }
+          *(bf16x8_t*)dst = pk;
         }
       } else {
-        const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
           if (col + e < p.N) {
-            float x = vv[e];
+            float x = v[e >> 2][e & 3];
             if (resid) x += resid[(long)row * p.ldr + col + e];
             store_from_f32<OutT>(out + (long)row * p.ldc + col + e, x);
           }

@@ -114,6 +114,17 @@ def test_gemm_bf16_random(ops, M, N, K):
     assert_close(got16, torch.nn.functional.gelu(want), 6e-3, "gemm_bf16 gelu→bf16")
 
 
+def test_gelu_poly_accuracy(ops):
+    # the bf16 GEMM epilogue evaluates GELU as relu(x) - u·(0.5 - u·P(u²)) (odic_common.h::gelu_poly4);
+    # feed exact values through an identity product and compare with the erf form over [-12, 12]
+    K = 64
+    x = torch.linspace(-12, 12, 64 * 4096).bfloat16().float().reshape(-1, K)
+    got = ops.gemm(dev(x).bfloat16(), dev(torch.eye(K)).bfloat16(), act=1, out_dtype=torch.float32).cpu()
+    want = torch.nn.functional.gelu(x.double())
+    err = (got.double() - want).abs().max().item()
+    assert err <= 6e-5, err
+
+
 # ------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("C", [96, 192, 512, 768, 1536, 3072, 6144])
 @pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
