@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=6)
     ap.add_argument("--decode-lanes", type=int, default=2)
+    ap.add_argument("--encode-lanes", type=int, default=1,
+                    help="encode graphs (one batch each) that may run concurrently on their own HIP streams")
+    ap.add_argument("--decode-group", type=int, default=1,
+                    help="consecutive batches searched together by one decode lane (rows per step kernel = group*batch*beam)")
     return ap.parse_args()
 
 
@@ -69,8 +73,8 @@ def build_model(device, precision):
 def roofline_pass(pipe, images):
     """One extra eager pass of the same workload with per-launch HIP events."""
     from on_device_image_captioning_amd import ops
-    g_enc, g_step = pipe.g_enc, pipe.g_step
-    pipe.g_enc, pipe.g_step = None, [None] * pipe.D           # eager launches: events bracket single kernels
+    g_encs, g_step = pipe.g_encs, pipe.g_step
+    pipe.g_encs, pipe.g_step = [None] * pipe.E, [None] * pipe.D   # eager launches: events bracket single kernels
     try:
         pipe(images)                           # warm
         torch.cuda.synchronize()
@@ -78,7 +82,7 @@ def roofline_pass(pipe, images):
             pipe(images)                       # one batch alone: encode then decode, no overlap
         torch.cuda.synchronize()
     finally:
-        pipe.g_enc, pipe.g_step = g_enc, g_step
+        pipe.g_encs, pipe.g_step = g_encs, g_step
     fam, shapes = {}, {}
     for name, flops, nbytes, s, e, detail in recs:
         ms = s.elapsed_time(e)
@@ -181,7 +185,8 @@ def main():
     torch.set_grad_enabled(False)
     model, sd, g = build_model(device, a.precision)
     pipe = CaptionPipeline(model, a.batch, a.beam, a.max_len, SOS, EOS, use_graphs=not a.no_graphs,
-                           decode_lanes=a.decode_lanes)
+                           decode_lanes=a.decode_lanes, decode_group=a.decode_group,
+                           encode_lanes=a.encode_lanes)
     images = W.synth_images(a.batch, g, seed=42 + rank).to(device)         # resident in HBM
 
     def finish_one():
@@ -197,7 +202,7 @@ def main():
         caps = None
         for _ in range(n):
             pipe.submit(images)
-            if pipe.full():
+            while pipe.full():
                 caps = finish_one()
         while pipe.outstanding():
             caps = finish_one()
@@ -231,7 +236,8 @@ def main():
                        "decoder_steps": pipe.steps, "weights": "synthetic xavier (Philox, seed 0)",
                        "backbone_precision": a.precision, "captioner_precision": "fp32",
                        "hip_graphs": not a.no_graphs, "parallelism": f"image-shard x{world}",
-                       "caption_len_check": min(len(c) for c in caps), "overlap": "encode(i+1) || decode(i) || decode(i-1) on three HIP streams"},
+                       "caption_len_check": min(len(c) for c in caps), "encode_lanes": pipe.E, "decode_lanes": pipe.D, "decode_group_batches": pipe.G,
+                       "overlap": "encode graph of batch i+1 || beam-search step graphs of earlier batches, one HIP stream each"},
         }
         if not a.no_roofline:
             fam = roofline_pass(pipe, images)

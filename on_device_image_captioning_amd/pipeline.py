@@ -27,16 +27,21 @@ class CaptionPipeline:
     """Software pipeline over consecutive batches on HIP streams:
 
         s_enc      encode graph of batch i+1          (compute-bound, fills the chip)
-        s_dec[0]   decode-step graph x(T-1), batch i   \\  ~40 tiny dependent kernels per step: latency-bound,
-        s_dec[1]   decode-step graph x(T-1), batch i-1 //  so two chains in flight hide each other's waits
+        s_dec[0]   decode-step graph x(T-1), group j   \\  ~40 tiny dependent kernels per step: latency-bound,
+        s_dec[1]   decode-step graph x(T-1), group j-1 //  so two chains in flight hide each other's waits
 
-    `submit()` only enqueues; `collect()` returns the captions of the oldest outstanding batch.  Every
-    batch is still processed exactly as in the reference (batch B through encoder and search); only
-    the scheduling across batches is overlapped."""
+    A decode GROUP is `decode_group` consecutive batches searched together (G·B images, G·B·k rows per
+    kernel): the step kernels are latency-bound at 48 rows, so G batches share one chain of launches.
+    Images never interact inside the search, so the captions are those of the per-batch search.
+
+    `submit()` only enqueues; `collect()` returns the captions of the oldest outstanding batch (and
+    launches a partially filled group if that batch is waiting in one).  Every batch is still
+    processed exactly as in the reference (encoder and search per image); only the scheduling
+    across batches is overlapped."""
 
     def __init__(self, model: CaptioningModel, batch: int, beam_size: int, max_seq_len: int, sos_idx: int,
                  eos_idx: int, use_graphs: bool = True, done_poll: int = 0, decode_lanes: int = 2,
-                 streams=None):
+                 streams=None, decode_group: int = 1, encode_lanes: int = 1):
         """done_poll = 0: never look at the `done` flag (fixed work per batch — benchmark mode with
         weights that never emit EOS); n > 0: host checks every n steps and stops early."""
         self.model, self.B, self.k = model, batch, beam_size
@@ -45,37 +50,49 @@ class CaptionPipeline:
         self.sos, self.eos = sos_idx, eos_idx
         self.done_poll = done_poll
         self.D = max(1, decode_lanes)
-        self.R = self.D + 1                                        # batches that may be outstanding
+        self.G = max(1, decode_group)
+        self.E = max(1, encode_lanes)                              # encode graphs that may be in flight together
+        self.NB = self.G * batch                                   # images per search launch
+        self.RG = self.D + 1                                       # result ring, in groups
+        self.R = self.RG * self.G                                  # batches that may be outstanding (upper bound)
         swin, cap = model._engines()
         self.swin, self.cap = swin, cap
         g, dv = cap.g, cap.device
         self.device = dv
-        self.img = torch.zeros(batch, g.swin_in_chans, g.swin_img_size, g.swin_img_size, dtype=torch.float32,
-                               device=dv)
+        self.imgs = [torch.zeros(batch, g.swin_in_chans, g.swin_img_size, g.swin_img_size, dtype=torch.float32,
+                                 device=dv) for _ in range(self.E)]
         S = g.stage_res(len(g.swin_depths) - 1) ** 2
         self.enc_len = torch.full((batch,), S, dtype=torch.int32, device=dv)
-        kvshape = (batch, S, 2 * g.N_dec * g.d_model)
-        self.kv_stage = torch.empty(kvshape, dtype=torch.float32, device=dv)    # written by the encode graph
-        self.kv = [torch.empty(kvshape, dtype=torch.float32, device=dv) for _ in range(self.D)]
-        self.states = [cap.new_state(batch, beam_size, self.T, self.kv[l], self.enc_len) for l in range(self.D)]
-        self.order = [torch.empty(batch, beam_size, dtype=torch.int32, device=dv) for _ in range(self.D)]
-        self.score = [torch.empty(batch, beam_size, dtype=torch.float32, device=dv) for _ in range(self.D)]
-        if streams is not None:                                    # (encode stream, [decode streams]) supplied by the caller
-            self.s_enc, self.s_dec = streams[0], list(streams[1])
+        self.enc_len_grp = torch.full((self.NB,), S, dtype=torch.int32, device=dv)
+        nkv = 2 * g.N_dec * g.d_model
+        self.kv_stages = [torch.empty(batch, S, nkv, dtype=torch.float32, device=dv)    # written by the encode graphs
+                          for _ in range(self.E)]
+        self.kv = [torch.empty(self.NB, S, nkv, dtype=torch.float32, device=dv) for _ in range(self.D)]
+        self.states = [cap.new_state(self.NB, beam_size, self.T, self.kv[l], self.enc_len_grp)
+                       for l in range(self.D)]
+        self.order = [torch.empty(self.NB, beam_size, dtype=torch.int32, device=dv) for _ in range(self.D)]
+        self.score = [torch.empty(self.NB, beam_size, dtype=torch.float32, device=dv) for _ in range(self.D)]
+        if streams is not None:                                    # ([encode streams], [decode streams]) supplied by the caller
+            self.s_encs = list(streams[0]) if isinstance(streams[0], (list, tuple)) else [streams[0]]
+            self.s_dec = list(streams[1])
         else:
-            self.s_enc = torch.cuda.Stream(device=dv)
+            self.s_encs = [torch.cuda.Stream(device=dv) for _ in range(self.E)]
             self.s_dec = [torch.cuda.Stream(device=dv) for _ in range(self.D)]
-        self.ev_enc = torch.cuda.Event()
-        self.ev_kv_taken = torch.cuda.Event()
-        self.ev_kv_taken.record()
-        # results ring (device) + pinned host mirrors
-        self.out_tok = [torch.zeros(batch, self.T, dtype=torch.int32, device=dv) for _ in range(self.R)]
-        self.out_len = [torch.zeros(batch, dtype=torch.int32, device=dv) for _ in range(self.R)]
-        self.host_tok = [torch.zeros(batch, self.T, dtype=torch.int32).pin_memory() for _ in range(self.R)]
-        self.host_len = [torch.zeros(batch, dtype=torch.int32).pin_memory() for _ in range(self.R)]
-        self.ev_done = [torch.cuda.Event() for _ in range(self.R)]
+        self.ev_enc = [torch.cuda.Event() for _ in range(self.E)]
+        self.ev_kv_taken = [torch.cuda.Event() for _ in range(self.E)]
+        for ev in self.ev_kv_taken:
+            ev.record()
+        # results ring (device, one slot per group) + pinned host mirrors
+        self.out_tok = [torch.zeros(self.NB, self.T, dtype=torch.int32, device=dv) for _ in range(self.RG)]
+        self.out_len = [torch.zeros(self.NB, dtype=torch.int32, device=dv) for _ in range(self.RG)]
+        self.host_tok = [torch.zeros(self.NB, self.T, dtype=torch.int32).pin_memory() for _ in range(self.RG)]
+        self.host_len = [torch.zeros(self.NB, dtype=torch.int32).pin_memory() for _ in range(self.RG)]
+        self.ev_done = [torch.cuda.Event() for _ in range(self.RG)]
         self._submitted = self._collected = 0
-        self.g_enc: Optional[torch.cuda.CUDAGraph] = None
+        self._gi = 0                 # index of the group being filled
+        self._gfill = 0              # batches already staged into it
+        self._where: List[Tuple[int, int]] = []    # outstanding batches, oldest first: (group index, position in group)
+        self.g_encs: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.E
         self.g_step: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.D
         if use_graphs:
             self._capture()
@@ -85,14 +102,30 @@ class CaptionPipeline:
     def state(self):
         return self.states[0]
 
+    @property
+    def s_enc(self):
+        return self.s_encs[0]
+
+    @property
+    def g_enc(self):
+        return self.g_encs[0]
+
+    @property
+    def img(self):
+        return self.imgs[0]
+
+    @property
+    def kv_stage(self):
+        return self.kv_stages[0]
+
     # -- the captured regions -------------------------------------------------------------------
-    def _encode(self) -> None:
-        feats = self.swin.forward(self.img, out_dtype=self.cap.cdt)
+    def _encode(self, e: int = 0) -> None:
+        feats = self.swin.forward(self.imgs[e], out_dtype=self.cap.cdt)
         if self.cap.cdt == torch.bfloat16:
             _, mem16 = self.cap.encode(feats, self.enc_len, want_bf16_mem=True)
-            self.cap.project_kv(mem16, out=self.kv_stage)
+            self.cap.project_kv(mem16, out=self.kv_stages[e])
         else:
-            self.cap.project_kv(self.cap.encode(feats, self.enc_len), out=self.kv_stage)
+            self.cap.project_kv(self.cap.encode(feats, self.enc_len), out=self.kv_stages[e])
 
     def _step(self, lane: int) -> None:
         self.cap.beam_step(self.states[lane], self.eos)
@@ -108,18 +141,20 @@ class CaptionPipeline:
 
     def _capture(self) -> None:
         torch.cuda.synchronize()
-        with torch.cuda.stream(self.s_enc), ops.autotune():      # warm-up: allocator, code load, tile autotune
-            self._encode()
+        with torch.cuda.stream(self.s_encs[0]), ops.autotune():  # warm-up: allocator, code load, tile autotune
+            self._encode(0)
         for lane in range(self.D):
             with torch.cuda.stream(self.s_dec[lane]):
-                self.s_dec[lane].wait_stream(self.s_enc)
-                self.kv[lane].copy_(self.kv_stage)
+                self.s_dec[lane].wait_stream(self.s_encs[0])
+                for p in range(self.G):
+                    self.kv[lane][p * self.B:(p + 1) * self.B].copy_(self.kv_stages[0])
                 self._reset(lane)
                 self._step(lane)
         torch.cuda.synchronize()
-        self.g_enc = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_enc, stream=self.s_enc):
-            self._encode()
+        for e in range(self.E):                                  # one graph (and private activation pool) per encode lane
+            self.g_encs[e] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_encs[e], stream=self.s_encs[e]):
+                self._encode(e)
         for lane in range(self.D):
             self._reset(lane)
             self.g_step[lane] = torch.cuda.CUDAGraph()
@@ -130,27 +165,46 @@ class CaptionPipeline:
     # -- public ---------------------------------------------------------------------------------
     def submit(self, images: torch.Tensor) -> None:
         """Enqueue one batch; never blocks the host (unless done_poll > 0)."""
-        if self._submitted - self._collected >= self.R:
-            raise RuntimeError(f"at most {self.R} batches may be outstanding; call collect() first")
-        slot = self._submitted % self.R
-        lane = self._submitted % self.D
+        if self.full():
+            raise RuntimeError(f"result ring full ({self.outstanding()} batches outstanding); call collect() first")
+        gi, gpos = self._gi, self._gfill
+        lane = gi % self.D
+        e = self._submitted % self.E
         cur = torch.cuda.current_stream()
-        with torch.cuda.stream(self.s_enc):
-            self.s_enc.wait_stream(cur)                          # `images` may have been produced there
-            self.s_enc.wait_event(self.ev_kv_taken)              # previous K/V hand-off finished
-            self.img.copy_(images, non_blocking=True)
-            if self.g_enc is not None:
-                self.g_enc.replay()
+        se = self.s_encs[e]
+        with torch.cuda.stream(se):
+            se.wait_stream(cur)                                  # `images` may have been produced there
+            se.wait_event(self.ev_kv_taken[e])                   # this lane's previous K/V hand-off finished
+            self.imgs[e].copy_(images, non_blocking=True)
+            if self.g_encs[e] is not None:
+                self.g_encs[e].replay()
             else:
-                self._encode()
-            self.ev_enc.record()
+                self._encode(e)
+            self.ev_enc[e].record()
         sd = self.s_dec[lane]
         with torch.cuda.stream(sd):
-            sd.wait_event(self.ev_enc)
-            self.kv[lane].copy_(self.kv_stage)
-            self.ev_kv_taken.record()
+            sd.wait_event(self.ev_enc[e])
+            self.kv[lane][gpos * self.B:(gpos + 1) * self.B].copy_(self.kv_stages[e])
+            self.ev_kv_taken[e].record()
+        self._where.append((gi, gpos))
+        self._submitted += 1
+        self._gfill += 1
+        if self._gfill == self.G:
+            self._launch_group()
+
+    def flush(self) -> None:
+        """Search a partially filled group now (its empty positions repeat the last staged batch)."""
+        if self._gfill:
+            self._launch_group()
+
+    def _launch_group(self) -> None:
+        gi, filled = self._gi, self._gfill
+        lane, gslot = gi % self.D, gi % self.RG
+        st = self.states[lane]
+        with torch.cuda.stream(self.s_dec[lane]):
+            for p in range(filled, self.G):
+                self.kv[lane][p * self.B:(p + 1) * self.B].copy_(self.kv[lane][(filled - 1) * self.B:filled * self.B])
             self._reset(lane)
-            st = self.states[lane]
             for t in range(self.steps):
                 if self.g_step[lane] is not None:
                     self.g_step[lane].replay()
@@ -159,21 +213,22 @@ class CaptionPipeline:
                 if self.done_poll and t >= 1 and (t + 1) % self.done_poll == 0 and t + 1 < self.steps \
                         and int(st.done.item()):
                     break
-            ops.beam_finalize(st.beam_state, self.order[lane], self.score[lane], self.B, self.k)
+            ops.beam_finalize(st.beam_state, self.order[lane], self.score[lane], self.NB, self.k)
             toks, lens = self._best_tokens(lane)
-            self.out_tok[slot].copy_(toks)
-            self.out_len[slot].copy_(lens)
-            self.host_tok[slot].copy_(self.out_tok[slot], non_blocking=True)
-            self.host_len[slot].copy_(self.out_len[slot], non_blocking=True)
-            self.ev_done[slot].record()
-        self._submitted += 1
+            self.out_tok[gslot].copy_(toks)
+            self.out_len[gslot].copy_(lens)
+            self.host_tok[gslot].copy_(self.out_tok[gslot], non_blocking=True)
+            self.host_len[gslot].copy_(self.out_len[gslot], non_blocking=True)
+            self.ev_done[gslot].record()
+        self._gi += 1
+        self._gfill = 0
 
     def _best_tokens(self, lane: int) -> Tuple[torch.Tensor, torch.Tensor]:
         st = self.states[lane]
         best = self.order[lane][:, 0].long()
-        bidx = torch.arange(self.B, device=best.device)
-        toks = st.tokens[bidx, best]                                       # [B, T]
-        lens = st.n_elem.view(self.B, self.k)[bidx, best]
+        bidx = torch.arange(self.NB, device=best.device)
+        toks = st.tokens[bidx, best]                                       # [G·B, T]
+        lens = st.n_elem.view(self.NB, self.k)[bidx, best]
         pad = torch.arange(self.T, device=best.device)[None, :] >= lens[:, None]
         return toks.masked_fill(pad, self.eos), lens
 
@@ -181,27 +236,37 @@ class CaptionPipeline:
         return self._submitted - self._collected
 
     def full(self) -> bool:
-        return self.outstanding() >= self.R
+        """True when the next submit() would reuse the result slot of a group not yet collected."""
+        return bool(self._where) and self._gi - self._where[0][0] >= self.RG
+
+    def _oldest(self) -> Tuple[int, int]:
+        if not self._where:
+            raise RuntimeError("nothing outstanding")
+        gi, gpos = self._where[0]
+        if gi == self._gi:                                       # still waiting in a partially filled group
+            self.flush()
+        return gi, gpos
 
     def collect_device(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """Device tensors (int32 [B,T] EOS-padded tokens, int32 [B] lengths) of the oldest outstanding
         batch, ordered after its decode on the CURRENT stream (for a following collective)."""
-        if self._collected >= self._submitted:
-            raise RuntimeError("nothing outstanding")
-        slot = self._collected % self.R
-        torch.cuda.current_stream().wait_event(self.ev_done[slot])
+        gi, gpos = self._oldest()
+        gslot = gi % self.RG
+        torch.cuda.current_stream().wait_event(self.ev_done[gslot])
+        self._where.pop(0)
         self._collected += 1
-        return self.out_tok[slot], self.out_len[slot]
+        rows = slice(gpos * self.B, (gpos + 1) * self.B)
+        return self.out_tok[gslot][rows], self.out_len[gslot][rows]
 
     def collect(self) -> List[List[int]]:
         """Captions (token-id lists) of the oldest outstanding batch; blocks until it is decoded."""
-        if self._collected >= self._submitted:
-            raise RuntimeError("nothing outstanding")
-        slot = self._collected % self.R
-        self.ev_done[slot].synchronize()
+        gi, gpos = self._oldest()
+        gslot = gi % self.RG
+        self.ev_done[gslot].synchronize()
+        self._where.pop(0)
         self._collected += 1
-        toks, lens = self.host_tok[slot], self.host_len[slot]
-        return [toks[b, :int(lens[b])].tolist() for b in range(self.B)]
+        toks, lens = self.host_tok[gslot], self.host_len[gslot]
+        return [toks[b, :int(lens[b])].tolist() for b in range(gpos * self.B, (gpos + 1) * self.B)]
 
     def __call__(self, images: torch.Tensor) -> List[List[int]]:
         self.submit(images)

@@ -292,6 +292,30 @@ def test_pipeline_matches_reference_best_caption(variant, graphs, poll):
     assert pipe(img) == want
 
 
+@pytest.mark.parametrize("group,lanes,poll", [(2, 2, 0), (3, 1, 4), (2, 1, 0)])
+def test_pipeline_decode_groups_match_reference(group, lanes, poll):
+    """`decode_group` batches searched by one chain of step kernels (G·B·k rows) give the per-batch
+    captions, including a partially filled group flushed by collect()."""
+    from on_device_image_captioning_amd.pipeline import CaptionPipeline
+    g = W.TINY
+    m = build_model("TINY", "eos")
+    store = np.load(os.path.join(GOLDEN, "tiny_eos.npz"))
+    want = [per[0] for per in unpad(store["beam3_T12.tokens"])]
+    img = W.synth_images(3, g).to(DEV)
+    flip = img.flip(0).contiguous()
+    pipe = CaptionPipeline(m, 3, 3, 12, TSOS, TEOS, done_poll=poll, decode_lanes=lanes, decode_group=group)
+    got, sent = [], []
+    for i in range(7):                                  # 7 batches: full groups + a partial tail
+        while pipe.full():
+            got.append(pipe.collect())
+        pipe.submit(flip if i % 3 == 1 else img)
+        sent.append(want[::-1] if i % 3 == 1 else want)
+    while pipe.outstanding():
+        got.append(pipe.collect())
+    assert got == sent
+    assert pipe(flip) == want[::-1]                     # a lone batch: group of one real + repeats
+
+
 # ----------------------------------------------------------------------------------------- F3: sampling
 def test_sampling_mode_logprobs_are_teacher_forced_logprobs():
     """mode='sampling' draws tokens with the device RNG (not reproducible against the reference's CPU

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Which decode kernels cost the encode graph the most when they run beside it?  For each candidate
+kernel: a graph of 64 back-to-back launches replays continuously on its own stream while the encode
+graph replays 6 times; prints the encode time per replay and the candidate's achieved launch rate."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+from on_device_image_captioning_amd import ops, weights as W
+from on_device_image_captioning_amd.pipeline import CaptionPipeline
+
+torch.set_grad_enabled(False)
+dev = torch.device("cuda", 0)
+model, sd, g = bench.build_model(dev, "bf16")
+pipe = CaptionPipeline(model, 16, 3, 20, 79, 77, decode_lanes=1)
+st = pipe.states[0]
+cap = pipe.cap
+N, d = st.N, g.d_model
+w = cap.dec[0]
+x = torch.randn(N, d, device=dev)
+h = torch.randn(N, g.ff, device=dev)
+ycat = torch.randn(N, 3 * d, device=dev)
+out_d = torch.empty(N, d, device=dev)
+out_5d = torch.empty(N, 5 * d, device=dev)
+out_ff = torch.empty(N, g.ff, device=dev)
+cands = {
+    "none": None,
+    "layernorm 48x512": lambda: ops.layernorm(x, w["n1w"], w["n1b"], M=N, C_=d, ldx=d),
+    "gemm dyn 512->2560 (160 blk)": lambda: ops.gemm(x, w["dyn_w"], w["dyn_b"], out=out_5d),
+    "gemm wq 512->512 (32 blk)": lambda: ops.gemm(x, w["wq"], w["bq"], out=out_d),
+    "gemm f1 512->2048 (128 blk)": lambda: ops.gemm(x, w["f1w"], w["f1b"], act=ops.ACT_RELU, out=out_ff),
+    "gemm f2 2048->512 (32 blk)": lambda: ops.gemm(h, w["f2w"], w["f2b"], out=out_d),
+    "gemm vocab 512->10000 (625 blk)": lambda: ops.gemm(x, cap.voc_w, cap.voc_b, out=st.logits),
+    "logsoftmax_topk": lambda: ops.logsoftmax_topk(st.logits, g.vocab_size, None, 0, st.cand_val, st.cand_idx, N,
+                                                   g.vocab_size, 3),
+    "cross_attn": lambda: ops.cross_attn_step(x, d, st.kv, st.kv.shape[2], 0, d, st.enc_len, st.row_valid, out_d, d, N,
+                                              st.n_img, st.S, d, g.num_heads),
+    "full decode step": lambda: pipe._step(0),
+}
+s2 = torch.cuda.Stream()
+NL = 64
+for name, fn in cands.items():
+    gr = None
+    if fn is not None:
+        with torch.cuda.stream(s2):
+            fn()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        nl = 4 if name == "full decode step" else NL
+        with torch.cuda.graph(gr, stream=s2):
+            for _ in range(nl):
+                fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nrep = 0
+    with torch.cuda.stream(s2):
+        k0.record()
+    with torch.cuda.stream(pipe.s_enc):
+        e0.record()
+    for i in range(6):
+        with torch.cuda.stream(pipe.s_enc):
+            pipe.g_enc.replay()
+        if gr is not None:
+            with torch.cuda.stream(s2):
+                for _ in range(8 if name != "full decode step" else 6):
+                    gr.replay()
+                    nrep += 1
+    with torch.cuda.stream(pipe.s_enc):
+        e1.record()
+    with torch.cuda.stream(s2):
+        k1.record()
+    torch.cuda.synchronize()
+    enc = e0.elapsed_time(e1) / 6
+    if gr is None:
+        print(f"{name:34s} encode {enc:7.3f} ms")
+    else:
+        per = 39 * 4 if name == "full decode step" else NL
+        kt = k0.elapsed_time(k1)
+        print(f"{name:34s} encode {enc:7.3f} ms | side stream busy {kt:7.2f} ms, {1e3 * kt / (nrep * per):6.2f} us per launch "
+              f"({nrep * per} launches)")

@@ -16,7 +16,10 @@ torch.set_grad_enabled(False)
 dev = torch.device("cuda", 0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 model, sd, g = bench.build_model(dev, "bf16")
-pipe = CaptionPipeline(model, B, 3, 20, 79, 77)
+D = int(os.environ.get("ODIC_LANES", "2"))
+G = int(os.environ.get("ODIC_GROUP", "1"))
+E = int(os.environ.get("ODIC_ENC_LANES", "1"))
+pipe = CaptionPipeline(model, B, 3, 20, 79, 77, decode_lanes=D, decode_group=G, encode_lanes=E)
 img = W.synth_images(B, g).to(dev)
 
 
@@ -43,12 +46,51 @@ def dec():
 
 def both():
     pipe.submit(img)
-    if pipe.full():
+    while pipe.full():
         pipe.collect()
 
 
 pipe(img)
-print(f"B={B}: encode graph alone {timeit(enc):.3f} ms | decode loop alone {timeit(dec):.3f} ms | "
-      f"overlapped step {timeit(both, 20):.3f} ms")
+print(f"B={B} enc_lanes={E} lanes={D} group={G}: encode graph alone {timeit(enc):.3f} ms | decode loop alone {timeit(dec):.3f} ms | "
+      f"overlapped step {timeit(both, 24):.3f} ms per batch")
 while pipe.outstanding():
     pipe.collect()
+
+
+def interference(n_enc=12):
+    """Encode graph replayed back to back while every decode lane replays its step graph continuously:
+    how much does each side slow the other down?"""
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    lane_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(D)]
+    nsteps = 12 * pipe.steps
+    for l in range(D):
+        with torch.cuda.stream(pipe.s_dec[l]):
+            pipe._reset(l)
+            lane_ev[l][0].record()
+    with torch.cuda.stream(pipe.s_enc):
+        ev0.record()
+    for i in range(max(n_enc, nsteps)):
+        if i < n_enc:
+            with torch.cuda.stream(pipe.s_enc):
+                pipe.g_enc.replay()
+        if i < nsteps:
+            for l in range(D):
+                with torch.cuda.stream(pipe.s_dec[l]):
+                    if i % pipe.steps == 0:
+                        pipe._reset(l)
+                    pipe.g_step[l].replay()
+    with torch.cuda.stream(pipe.s_enc):
+        ev1.record()
+    for l in range(D):
+        with torch.cuda.stream(pipe.s_dec[l]):
+            lane_ev[l][1].record()
+    torch.cuda.synchronize()
+    enc_ms = ev0.elapsed_time(ev1) / n_enc
+    dec = [lane_ev[l][0].elapsed_time(lane_ev[l][1]) / 12 for l in range(D)]
+    print(f"  concurrent: encode {enc_ms:.3f} ms each ({n_enc} replays) | decode loops " +
+          ", ".join(f"{d:.3f}" for d in dec) + " ms per 19-step search (12 searches per lane)")
+
+
+if os.environ.get("ODIC_INTERFERENCE"):
+    interference()
