@@ -40,7 +40,7 @@ extern "C" {
 #define ODIC_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ODIC_ABI_VERSION 4
+#define ODIC_ABI_VERSION 5
 int odic_abi_version(void);
 
 /* Human-readable build string ("gfx950 hipcc ..."), static storage. */
@@ -117,14 +117,15 @@ int odic_patch_embed(const float* img, const float* w, const float* b, const flo
  *   qkv  `dtype` [B*res*res, 3C]   token-major output of the qkv Linear, columns (3, heads, 32)
  *   bias_table fp32 [(2ws-1)², heads]   relative_position_bias_table; the index buffer (:163-173)
  *        and the SW-MSA mask (:281-297, values 0/-100) are recomputed from coordinates.
- *   bias_dense_log2 (optional, bf16 path) fp32 [heads, ws², ws²] = bias_table[relative_position_index]
- *        (the gather of :196-198) multiplied by log2(e); enables the faster kernel (base-2 softmax,
- *        no index arithmetic).  NULL → the table is used.
+ *   bias_dense_prescaled (optional, bf16 path) fp32 [heads, ws², ws²] = bias_table[relative_position_index]
+ *        (the gather of :196-198) DIVIDED BY `scale`: the fast kernel loads it as the accumulator
+ *        init of the q·kᵀ MFMA and applies scale·log2(e) afterwards (base-2 softmax, no bias
+ *        arithmetic, no index arithmetic).  NULL → the table is used.
  *   out  `dtype` [B*res*res, C]    softmax(q·kᵀ·scale + bias + mask)·v, heads concatenated,
  *        written back at the un-shifted token positions (ready for the proj Linear).
  * head_dim is 32 (every Swin-L stage), ws*ws <= 144, res % ws == 0, 0 <= shift < ws.
  * ------------------------------------------------------------------------------------------- */
-int odic_window_attention(const void* qkv, const float* bias_table, const float* bias_dense_log2,
+int odic_window_attention(const void* qkv, const float* bias_table, const float* bias_dense_prescaled,
                           void* out, int32_t B, int32_t res, int32_t C, int32_t heads, int32_t ws,
                           int32_t shift, float scale, int32_t dtype, void* stream);
 

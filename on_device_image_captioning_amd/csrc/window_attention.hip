@@ -291,21 +291,36 @@ __global__ __launch_bounds__(192, 2) void window_attention_bf16_kernel(WinParams
 
 
 // =================================================================================================
-// bf16 MFMA kernel, v2 (used when the caller supplies the dense bias):
+// bf16 MFMA kernel, v2 (used when the caller supplies the dense pre-scaled bias).  The kernel is
+// VALU-issue-bound (36 scores per lane and query tile: v_exp_f32 alone is 144 of ~250 issue slots),
+// so everything around the exponentials is squeezed:
 //   * K and V are gathered straight into LDS by LDS-DMA (global_load_lds_dwordx4: per-lane source
 //     address = the window's token row, lane-linear destination = row-major [144][32]); no VGPR
 //     round trip and no transposing stores: V is consumed through ds_read_b64_tr_b16.
-//   * one 16-query tile at a time per wave: 36 score registers instead of 108 → 4+ blocks per CU.
-//   * softmax in base 2: scores = acc·(scale·log2e) + bias_dense (pre-multiplied by log2e on the
-//     host, already gathered through relative_position_index) → v_exp_f32 directly, 5 VALU per score.
+//   * the bias is the ACCUMULATOR INIT of the score MFMA: the host packs bias/scale (fp32, gathered
+//     through relative_position_index), the kernel loads it straight into the 36 accumulator
+//     registers and K·Qᵀ lands on top → no bias registers, no bias FMAs.  The next tile's bias (and
+//     its Q fragment) is requested as soon as the exponentials have freed those registers, under
+//     the P·V MFMAs and the output stores of the current tile.
+//   * softmax in base 2 on the raw accumulators: row max by v_max3_f32, then ONE packed FMA per
+//     score pair (acc·scale·log2e − max·scale·log2e) feeding v_exp_f32; row sums by packed adds;
+//     P is rounded to bf16 pairs as it is produced (18 registers).
 //   * the SW-MSA mask costs nothing on interior windows (wave-uniform branch); edge windows compare
 //     4 packed region ids per LDS word.
+//   96 registers → 5 waves per SIMD, six 3-wave blocks per CU.
 // =================================================================================================
 typedef __attribute__((ext_vector_type(4))) short v4s_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__global__ __launch_bounds__(192, 4) void window_attention_bf16_v2_kernel(WinParams p) {
+__device__ __forceinline__ float max3f(float a, float b, float c) {      // inputs are MFMA results: canonical
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+__global__ __launch_bounds__(192, 5) void window_attention_bf16_v2_kernel(WinParams p) {
   __shared__ __attribute__((aligned(16))) bf16_raw Ks[MAXN][HD];        // 9216 B
   __shared__ __attribute__((aligned(16))) bf16_raw Vs[MAXN + 16][HD];   // 10240 B (rows 144..159 zero)
   __shared__ int rows[MAXN];
@@ -345,40 +360,40 @@ __global__ __launch_bounds__(192, 4) void window_attention_bf16_v2_kernel(WinPar
       __builtin_amdgcn_global_load_lds((gptr_t)(src + 2 * p.C), (lptr_t)((char*)&Vs[0][0] + blk * 1024), 16, 0, 0);
     }
   }
-  // ---- Q fragments (B operand of Sᵀ = K·Qᵀ): Q[query = fr][d = 8·fq ..]
   const int fr = lane & 15, fq = lane >> 4;
-  bf16x8_t qf[3];
+  const float scale2 = p.scale * 1.4426950408889634f;
+  const float mask_acc = 100.0f / p.scale;                              // -100 in accumulator units
+  bf16_raw* out = (bf16_raw*)p.out;
+  // transposed-read addresses of V: lane (fr = 4q+p) of 16-lane group fq supplies row r0+q, cols 4p..4p+3
+  const int voff = ((4 * fq + (fr >> 2)) * HD + 4 * (fr & 3)) * 2;
+  const float* bhead = p.bias_dense + (long)head * MAXN * MAXN + fq * 4;
+
+  // first tile: bias → accumulators and Q fragment (B operand of Sᵀ = K·Qᵀ: Q[query = fr][d = 8·fq ..])
+  f32x4_t sc[9];
+  bf16x8_t q;
+  {
+    const int qn = wave * 48 + fr;
 #pragma unroll
-  for (int qt = 0; qt < 3; ++qt)
-    qf[qt] = *(const bf16x8_t*)(qkv + (long)rows[(wave * 3 + qt) * 16 + fr] * ld + head * HD + fq * 8);
+    for (int kt = 0; kt < 9; ++kt) sc[kt] = *(const f32x4_t*)(bhead + (long)qn * MAXN + kt * 16);
+    q = *(const bf16x8_t*)(qkv + (long)rows[qn] * ld + head * HD + fq * 8);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const float scale2 = p.scale * 1.4426950408889634f;
-  bf16_raw* out = (bf16_raw*)p.out;
-  // transposed-read addresses of V: lane (fr = 4q+p) of 16-lane group fq supplies row r0+q, cols 4p..4p+3
-  const char* vbase = (const char*)&Vs[0][0] + ((4 * fq + (fr >> 2)) * HD + 4 * (fr & 3)) * 2;
-
-#pragma unroll 1
+#pragma unroll
   for (int qt = 0; qt < 3; ++qt) {
     const int qn = (wave * 3 + qt) * 16 + fr;
-    const float* brow = p.bias_dense + ((long)head * MAXN + qn) * MAXN + fq * 4;
-    float4 bias[9];
-#pragma unroll
-    for (int kt = 0; kt < 9; ++kt) bias[kt] = *(const float4*)(brow + kt * 16);
-
-    f32x4_t sc[9];
-    const bf16x8_t q = qt == 0 ? qf[0] : (qt == 1 ? qf[1] : qf[2]);
-#pragma unroll
-    for (int kt = 0; kt < 9; ++kt) {
-      const bf16x8_t kf = *(const bf16x8_t*)&Ks[kt * 16 + fr][fq * 8];
-      sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, q, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-    }
-    float m = -INFINITY;
+    const int orow = rows[qn];
+    // (the K / V fragment addresses are made opaque once per tile: otherwise hipcc hoists all 29
+    //  loop-invariant LDS reads out of the tile loop and parks 76 registers on them)
+    int koff = (fr * HD + fq * 8) * 2, vo = voff;
+    asm volatile("" : "+v"(koff), "+v"(vo));
+    const char* kbase = (const char*)&Ks[0][0] + koff;
+    const char* vbase = (const char*)&Vs[0][0] + vo;
 #pragma unroll
     for (int kt = 0; kt < 9; ++kt) {
-      sc[kt][0] = fmaf(sc[kt][0], scale2, bias[kt].x); sc[kt][1] = fmaf(sc[kt][1], scale2, bias[kt].y);
-      sc[kt][2] = fmaf(sc[kt][2], scale2, bias[kt].z); sc[kt][3] = fmaf(sc[kt][3], scale2, bias[kt].w);
+      const bf16x8_t kf = *(const bf16x8_t*)(kbase + kt * 16 * HD * 2);
+      sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, q, sc[kt], 0, 0, 0);
     }
     if (masked) {
       const unsigned my = rids[qn];
@@ -387,41 +402,59 @@ __global__ __launch_bounds__(192, 4) void window_attention_bf16_v2_kernel(WinPar
         const unsigned kr = *(const unsigned*)&rids[kt * 16 + fq * 4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (((kr >> (8 * j)) & 0xff) != my) sc[kt][j] -= 144.26950408889634f;          // -100 · log2e
+          if (((kr >> (8 * j)) & 0xff) != my) sc[kt][j] -= mask_acc;
       }
     }
+    float m = max3f(sc[0][0], sc[0][1], sc[0][2]);
+    m = max3f(m, sc[0][3], sc[1][0]);
+    m = max3f(m, sc[1][1], sc[1][2]);
 #pragma unroll
-    for (int kt = 0; kt < 9; ++kt) m = fmaxf(fmaxf(m, fmaxf(sc[kt][0], sc[kt][1])), fmaxf(sc[kt][2], sc[kt][3]));
+    for (int kt = 2; kt < 9; kt += 2) {                                  // (sc[kt-1][3], sc[kt][0..3], sc[kt+1][0..2]) pairs
+      m = max3f(m, sc[kt - 1][3], sc[kt][0]);
+      m = max3f(m, sc[kt][1], sc[kt][2]);
+      if (kt + 1 < 9) {
+        m = max3f(m, sc[kt][3], sc[kt + 1][0]);
+        m = max3f(m, sc[kt + 1][1], sc[kt + 1][2]);
+      } else {
+        m = fmaxf(m, sc[kt][3]);
+      }
+    }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.f;
+    const f32x2_t s2 = {scale2, scale2};
+    const f32x2_t c2 = {-m * scale2, -m * scale2};
+    f32x2_t lsum = {0.f, 0.f};
+    bf16x4_t pk[9];
 #pragma unroll
     for (int kt = 0; kt < 9; ++kt) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float e = __builtin_amdgcn_exp2f(sc[kt][j] - m);
-        sc[kt][j] = e;
-        l += e;
+      for (int h = 0; h < 2; ++h) {
+        const f32x2_t a = f32x2_t{sc[kt][2 * h], sc[kt][2 * h + 1]} * s2 + c2;
+        const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        lsum += e;
+        pk[kt][2 * h] = (short)f32_to_bf16(e[0]);
+        pk[kt][2 * h + 1] = (short)f32_to_bf16(e[1]);
       }
     }
+    // the accumulators are free: request the next tile's bias and Q under the P·V work below
+    if (qt < 2) {
+      const int qn1 = qn + 16;
+#pragma unroll
+      for (int kt = 0; kt < 9; ++kt) sc[kt] = *(const f32x4_t*)(bhead + (long)qn1 * MAXN + kt * 16);
+      q = *(const bf16x8_t*)(qkv + (long)rows[qn1] * ld + head * HD + fq * 8);
+    }
+    float l = lsum[0] + lsum[1];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    const float inv_l = 1.0f / l;
+    const float inv_l = __builtin_amdgcn_rcpf(l);
 
     // Oᵀ = Vᵀ·Pᵀ : K-slot (fq, e) of step s ↔ key 32s + 16(e>>2) + 4fq + (e&3) on both operands
     f32x4_t oacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int s5 = 0; s5 < 5; ++s5) {
-      bf16x8_t pf;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pf[e] = (short)f32_to_bf16(sc[2 * s5][e]);
-      if (s5 < 4) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pf[4 + e] = (short)f32_to_bf16(sc[2 * s5 + 1][e]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pf[4 + e] = 0;
-      }
+      const bf16x4_t lo4 = pk[2 * s5];
+      const bf16x4_t hi4 = s5 < 4 ? pk[2 * s5 + (s5 < 4)] : bf16x4_t{0, 0, 0, 0};
+      const bf16x8_t pf = bf16x8_t{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -432,20 +465,20 @@ __global__ __launch_bounds__(192, 4) void window_attention_bf16_v2_kernel(WinPar
         oacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[nt], 0, 0, 0);
       }
     }
-    bf16_raw* dst = out + (long)rows[qn] * p.C + head * HD + fq * 4;
+    bf16_raw* dst = out + (long)orow * p.C + head * HD + fq * 4;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      ushort4 pk;
-      pk.x = f32_to_bf16(oacc[nt][0] * inv_l); pk.y = f32_to_bf16(oacc[nt][1] * inv_l);
-      pk.z = f32_to_bf16(oacc[nt][2] * inv_l); pk.w = f32_to_bf16(oacc[nt][3] * inv_l);
-      *(ushort4*)(dst + nt * 16) = pk;
+      ushort4 o4;
+      o4.x = f32_to_bf16(oacc[nt][0] * inv_l); o4.y = f32_to_bf16(oacc[nt][1] * inv_l);
+      o4.z = f32_to_bf16(oacc[nt][2] * inv_l); o4.w = f32_to_bf16(oacc[nt][3] * inv_l);
+      *(ushort4*)(dst + nt * 16) = o4;
     }
   }
 }
 
 }  // namespace
 
-extern "C" int odic_window_attention(const void* qkv, const float* bias_table, const float* bias_dense_log2,
+extern "C" int odic_window_attention(const void* qkv, const float* bias_table, const float* bias_dense_prescaled,
                                      void* out, int32_t B, int32_t res, int32_t C, int32_t heads, int32_t ws,
                                      int32_t shift, float scale, int32_t dtype, void* stream) {
   if (!qkv || !bias_table || !out) return ODIC_ENULL;
@@ -453,7 +486,7 @@ extern "C" int odic_window_attention(const void* qkv, const float* bias_table, c
     return ODIC_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return ODIC_EINVAL;
   WinParams p;
-  p.qkv = qkv; p.table = bias_table; p.bias_dense = bias_dense_log2; p.out = out; p.B = B; p.res = res; p.C = C; p.heads = heads;
+  p.qkv = qkv; p.table = bias_table; p.bias_dense = bias_dense_prescaled; p.out = out; p.B = B; p.res = res; p.C = C; p.heads = heads;
   p.ws = ws; p.shift = shift; p.nwin_side = res / ws; p.scale = scale;
   dim3 grid(B * p.nwin_side * p.nwin_side, heads), block(192);
   hipStream_t s = (hipStream_t)stream;
@@ -461,7 +494,7 @@ extern "C" int odic_window_attention(const void* qkv, const float* bias_table, c
     hipLaunchKernelGGL(window_attention_f32_kernel, grid, block, 0, s, p);
   } else if (dtype == ODIC_BF16) {
     if (ws != 12) return ODIC_EUNSUPPORTED;      // MFMA tiling is specialised for N = 144
-    if (bias_dense_log2 && (long)B * res * res < 2147483647L && !(((uintptr_t)bias_dense_log2) & 15)) {
+    if (bias_dense_prescaled && (long)B * res * res < 2147483647L && !(((uintptr_t)bias_dense_prescaled) & 15)) {
       const int nwin = B * p.nwin_side * p.nwin_side;
       hipLaunchKernelGGL(window_attention_bf16_v2_kernel, dim3(((nwin + 7) / 8) * 8 * heads), block, 0, s, p);
     }
