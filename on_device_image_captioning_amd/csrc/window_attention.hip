@@ -495,6 +495,9 @@ extern "C" int odic_window_attention(const void* qkv, const float* bias_table, c
   } else if (dtype == ODIC_BF16) {
     if (ws != 12) return ODIC_EUNSUPPORTED;      // MFMA tiling is specialised for N = 144
     if (bias_dense_prescaled && (long)B * res * res < 2147483647L && !(((uintptr_t)bias_dense_prescaled) & 15)) {
+      // (a persistent, double-buffered variant — one head x several windows per block — measured
+      //  slower at every stage: with ~0.5 us of work per window a prefetch distance of one window does
+      //  not cover the gather latency, and six independent 3-wave blocks per CU keep more bytes in flight)
       const int nwin = B * p.nwin_side * p.nwin_side;
       hipLaunchKernelGGL(window_attention_bf16_v2_kernel, dim3(((nwin + 7) / 8) * 8 * heads), block, 0, s, p);
     }
