@@ -70,11 +70,15 @@ typedef struct odic_gemm_args {
   int32_t in_dtype;   /* dtype of A and W */
   int32_t out_dtype;  /* dtype of out */
   int32_t tile_cfg;   /* bf16 only: tile configuration 0..11 (see csrc/gemm_bf16.hip), -1 = built-in choice */
-  /* Optional fused LayerNorm of the A operand (fp32 skinny-M path only: M <= 192, K % 16 == 0):
-   * A is then the un-normalised fp32 rows and the product is LayerNorm(A; ln_gamma, ln_beta, ln_eps)·Wᵀ.
+  /* Optional LayerNorm of the A operand, folded (fp32 skinny-M path only: M <= 192, K % 16 == 0,
+   * bias_axis 0).  The caller prepares  W' = W·diag(gamma),  ln_colsum[n] = Σ_k W'[n][k]  and
+   * bias' = bias + W·beta, passes W' / bias' as W / bias, and the kernel computes
+   *     out = act(rstd[m]·(alpha·A·W'ᵀ − mean[m]·ln_colsum) + bias') + residual
+   *         = act(LayerNorm(A; gamma, beta, ln_eps)·Wᵀ + bias) + residual
+   * with mean/rstd the moments of row m of the RAW fp32 A, accumulated from the operand fragments.
    * Replaces the separate norm_1/2/3 + dec_reduce_norm launches of the decoder step
    * (layers.py:225,228,232; End_ExpansionNet_v2.py:135).  NULL = plain GEMM. */
-  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  const float* ln_colsum; float ln_eps;
 } odic_gemm_args;
 int odic_gemm(const odic_gemm_args* args, void* stream);
 

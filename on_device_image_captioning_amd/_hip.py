@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
                 ("strideR", C.c_int64), ("strideC", C.c_int64),
                 ("alpha", C.c_float), ("act", C.c_int32), ("bias_axis", C.c_int32),
                 ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile_cfg", C.c_int32),
-                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float)]
+                ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float)]
 
 
 class BeamState(C.Structure):

@@ -265,7 +265,7 @@ int g_force_cfg = -1;      // test / tuning hook: odic_gemm_bf16_force_config()
 extern "C" void odic_gemm_bf16_force_config(int cfg) { g_force_cfg = cfg; }
 
 int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
-  if (a->ln_gamma) return ODIC_EUNSUPPORTED;
+  if (a->ln_colsum) return ODIC_EUNSUPPORTED;
   if (a->K % 64 != 0 || a->lda % 8 != 0 || a->ldw % 8 != 0) return ODIC_EINVAL;
   if (((uintptr_t)a->A & 15) || ((uintptr_t)a->W & 15)) return ODIC_EINVAL;
   if ((a->strideA % 8) || (a->strideW % 8)) return ODIC_EINVAL;

@@ -25,7 +25,7 @@ struct Params {
   long lda, ldw, ldr, ldc;
   long strideA, strideW, strideBias, strideR, strideC;
   float alpha; int act; int bias_axis; int vec_ok;
-  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  const float* ln_colsum; float ln_eps;
 };
 
 __device__ __forceinline__ float4 load4(const float* base, long ld, int row, int nrows, int k, int K,
@@ -126,131 +126,138 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(Params p) {
 
 // ---------------------------------------------------------------------------------------------
 // Skinny-M variant (decoder steps: M = images x beams = 48..192 rows against 0.25-20 MB weights).
-// These products are weight-streaming and latency-bound, so the grid is cut for parallelism:
-//   * one block per 16 output columns, every block covers ALL M rows (MT = ceil(M/16) MFMA tiles);
-//   * the block's waves split K between them (in-block split-K), each wave streams its K-slice of
-//     the 16 W rows straight from global memory into MFMA operands (no LDS round trip: W is read
-//     once, A is L2-resident) as float4 loads = 4 MFMA K-steps per load;
-//   * partial accumulators are summed through LDS, then the usual epilogue.
-// K-order inside an MFMA is permuted (slot (kq, s) ↔ k = k0 + 4·kq + s) identically on both
+// These products are weight-streaming and latency-bound, so the grid is cut for parallelism and
+// every wave is kept SHORT (the step chain runs beside the encoder's GEMM blocks: a long-lived wave
+// delays a whole GEMM tile):
+//   * one block per 16 output columns, covering ALL M rows (MT = ceil(M/16) MFMA row tiles);
+//   * waves = KS x MS: wave (ks, ms) owns the K-slice ks and MTW of the row tiles; it streams its
+//     slice of the 16 W rows and of its A rows straight from global memory into MFMA operands (no
+//     LDS round trip: W is read once per block, A is L2-resident) as float4 loads = 4 MFMA K-steps
+//     per load, a whole round (UN x 16 of K) issued at once and the next round prefetched before
+//     the MFMAs of the current one;
+//   * partial accumulators are summed through LDS (KS x MT KiB), then the usual epilogue.
+// K-order inside an MFMA is permuted (slot (kq, s) <-> k = k0 + 4·kq + s) identically on both
 // operands, which only changes the summation order.
+//
+// Folded LayerNorm (FOLD): with W' = W·diag(gamma), colsum[n] = Σ_k W'[n][k] and
+// bias' = bias + W·beta prepared by the caller,
+//     LayerNorm(a)·Wᵀ + bias = rstd·(a·W'ᵀ − mean·colsum) + bias'
+// so the product runs on the RAW rows and only the epilogue needs the row moments — which every
+// wave accumulates for free from the A fragments it loads anyway (Σa, Σa² over its K-slice).
 // ---------------------------------------------------------------------------------------------
-template <int MT, bool LN, typename OutT>
-__global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int kslice) {
-  extern __shared__ float red[];                   // [nwaves][MT][4][64]  (+ [2][MT*16] row moments if LN)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+template <int MTW, int UN, bool FOLD, typename OutT>
+__global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int kslice, int KS, int MT) {
+  extern __shared__ float red[];                   // [KS][MT][4][64] partial tiles (+ [KS][MT*16][2] row sums if FOLD)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ks = wave % KS, ms = wave / KS;
   const int n0 = blockIdx.x * 16;
   const long bz = blockIdx.z;
   const float* A = p.A + bz * p.strideA;
   const float* W = p.W + bz * p.strideW;
   const int fr = lane & 15, fq = lane >> 4;
-  const int k_begin = wave * kslice, k_end = min(p.K, k_begin + kslice);
+  const int k_begin = ks * kslice, k_end = min(p.K, k_begin + kslice);
+  const int t0 = ms * MTW;                          // first row tile of this wave
 
-  f32x4_t acc[MT];
+  f32x4_t acc[MTW];
+  float sx[MTW], sxx[MTW];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // fused LayerNorm of A: every block recomputes the (tiny, L2-resident) row moments — wave w owns rows
-  // w, w+nwaves, ...; two-pass mean / centred variance with the row held in registers.
-  float* ln_mean = red + nwaves * MT * 256;
-  float* ln_rstd = ln_mean + MT * 16;
-  if constexpr (LN) {
-    // one 16-lane group per row (blockDim/16 rows per pass), the row slice held in registers
-    const int grp = tid >> 4, gl = tid & 15, ngrp = blockDim.x >> 4;
-    for (int r0 = 0; r0 < p.M; r0 += ngrp) {
-      const int r = r0 + grp;
-      const float* xr = A + (long)min(r, p.M - 1) * p.lda;
-      float4 v[16];                                  // K <= 1024: 16 lanes x 16 float4
-      float sm = 0.f;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int c = (gl + 16 * t) * 4;
-        v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < p.K) { v[t] = *(const float4*)(xr + c); sm += (v[t].x + v[t].y) + (v[t].z + v[t].w); }
-      }
-      sm += __shfl_xor(sm, 8, 64); sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 1, 64);
-      const float mean = sm / (float)p.K;
-      float q = 0.f;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int c = (gl + 16 * t) * 4;
-        if (c < p.K) {
-          const float a0 = v[t].x - mean, a1 = v[t].y - mean, a2 = v[t].z - mean, a3 = v[t].w - mean;
-          q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-        }
-      }
-      q += __shfl_xor(q, 8, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 1, 64);
-      if (gl == 0 && r < p.M) { ln_mean[r] = mean; ln_rstd[r] = rsqrtf(q / (float)p.K + p.ln_eps); }
-    }
-    __syncthreads();
-  }
-  float mu[MT], rs[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    mu[i] = 0.f; rs[i] = 1.f;
-    if constexpr (LN) { const int m = min(i * 16 + fr, p.M - 1); mu[i] = ln_mean[m]; rs[i] = ln_rstd[m]; }
-  }
+  for (int i = 0; i < MTW; ++i) { acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; sx[i] = 0.f; sxx[i] = 0.f; }
 
   const bool wn_ok = (n0 + fr) < p.N;
   const float* wrow = W + (long)min(n0 + fr, p.N - 1) * p.ldw + 4 * fq;
-  const float* arow[MT];
-  bool am_ok[MT];
+  const float* arow[MTW];
+  bool am_ok[MTW];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = i * 16 + fr;
+  for (int i = 0; i < MTW; ++i) {
+    const int m = (t0 + i) * 16 + fr;
     am_ok[i] = m < p.M;
     arow[i] = A + (long)min(m, p.M - 1) * p.lda + 4 * fq;
   }
-  // All loads of a 64-deep K run are issued before the first MFMA (these kernels are latency-bound:
-  // the more requests in flight per wave the better); guards are applied on the loaded values.
-  constexpr int UN = (MT <= 4) ? 4 : 2;
-  for (int k = k_begin; k < k_end; k += 16 * UN) {
-    float4 w4[UN], a4[UN][MT];
+  float4 w4[2][UN], a4[2][UN][MTW];
+  auto load_round = [&](int buf, int k) {            // addresses clamped, values masked in compute()
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int kk = min(k + 16 * u, p.K - 16);          // clamped address, masked below
-      w4[u] = *(const float4*)(wrow + kk);
+      const int kk = min(k + 16 * u, p.K - 16);
+      w4[buf][u] = *(const float4*)(wrow + kk);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a4[u][i] = *(const float4*)(arow[i] + kk);
+      for (int i = 0; i < MTW; ++i) a4[buf][u][i] = *(const float4*)(arow[i] + kk);
     }
+  };
+  auto compute = [&](int buf, int k) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      if (k + 16 * u >= k_end || !wn_ok) w4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 g4, b4;
-      if constexpr (LN) {
-        const int kk = min(k + 16 * u, p.K - 16) + 4 * fq;
-        g4 = *(const float4*)(p.ln_gamma + kk); b4 = *(const float4*)(p.ln_beta + kk);
-      }
+      const bool live = k + 16 * u < k_end;
+      float4 w = w4[buf][u];
+      if (!live || !wn_ok) w = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        if constexpr (LN) {
-          a4[u][i].x = (a4[u][i].x - mu[i]) * rs[i] * g4.x + b4.x; a4[u][i].y = (a4[u][i].y - mu[i]) * rs[i] * g4.y + b4.y;
-          a4[u][i].z = (a4[u][i].z - mu[i]) * rs[i] * g4.z + b4.z; a4[u][i].w = (a4[u][i].w - mu[i]) * rs[i] * g4.w + b4.w;
+      for (int i = 0; i < MTW; ++i) {
+        float4 a = a4[buf][u][i];
+        if (!live || !am_ok[i]) a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (FOLD) {
+          sx[i] += (a.x + a.y) + (a.z + a.w);
+          sxx[i] += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
         }
-        if (!am_ok[i]) a4[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][i].x, w4[u].x, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][i].y, w4[u].y, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][i].z, w4[u].z, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][i].w, w4[u].w, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc[i], 0, 0, 0);
+      }
+    }
+  };
+  constexpr int STEP = 16 * UN;
+  if (t0 < MT && k_begin < k_end) {
+    load_round(0, k_begin);
+    for (int k = k_begin; k < k_end; k += 2 * STEP) {
+      if (k + STEP < k_end) load_round(1, k + STEP);
+      compute(0, k);
+      if (k + STEP < k_end) {
+        if (k + 2 * STEP < k_end) load_round(0, k + 2 * STEP);
+        compute(1, k + STEP);
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < MTW; ++i) {
+    if (t0 + i < MT) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) red[((wave * MT + i) * 4 + j) * 64 + lane] = acc[i][j];
+      for (int j = 0; j < 4; ++j) red[((ks * MT + t0 + i) * 4 + j) * 64 + lane] = acc[i][j];
+    }
+  }
+  float* rsum = red + KS * MT * 256;               // [KS][MT*16][2]
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      float a = sx[i], b = sxx[i];
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+      if (fq == 0 && t0 + i < MT) {
+        rsum[((ks * MT + t0 + i) * 16 + fr) * 2 + 0] = a;
+        rsum[((ks * MT + t0 + i) * 16 + fr) * 2 + 1] = b;
+      }
+    }
+  }
   __syncthreads();
 
   const float* bias = p.bias ? p.bias + bz * p.strideBias : nullptr;
   const float* resid = p.residual ? p.residual + bz * p.strideR : nullptr;
   OutT* out = (OutT*)p.out + bz * p.strideC;
+  const float inv_k = 1.0f / (float)p.K;
   for (int e = tid; e < MT * 256; e += blockDim.x) {
     const int i = e >> 8, j = (e >> 6) & 3, l = e & 63;
     float v = 0.f;
-    for (int w = 0; w < nwaves; ++w) v += red[((w * MT + i) * 4 + j) * 64 + l];
-    const int row = i * 16 + (l >> 4) * 4 + j, col = n0 + (l & 15);
+    for (int w = 0; w < KS; ++w) v += red[((w * MT + i) * 4 + j) * 64 + l];
+    const int r16 = (l >> 4) * 4 + j;
+    const int row = i * 16 + r16, col = n0 + (l & 15);
     if (row < p.M && col < p.N) {
       v *= p.alpha;
+      if constexpr (FOLD) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int w = 0; w < KS; ++w) { s1 += rsum[((w * MT + i) * 16 + r16) * 2]; s2 += rsum[((w * MT + i) * 16 + r16) * 2 + 1]; }
+        const float mean = s1 * inv_k;
+        const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
+        v = (v - mean * p.ln_colsum[col]) * rsqrtf(var + p.ln_eps);
+      }
       if (bias) v += p.bias_axis ? bias[row] : bias[col];
       v = apply_act<false>(v, p.act);
       if (resid) v += resid[(long)row * p.ldr + col];
@@ -259,23 +266,25 @@ __global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int ksl
   }
 }
 
-template <int MT>
+template <int MTW, int UN>
 static void launch_skinny(const Params& p, int out_dtype, int batch, hipStream_t stream) {
-  // waves: aim at K-slices of ~64, at most 16 waves, LDS for the reduction <= 48 KiB
-  int nw = (p.K + 63) / 64;
-  if (nw > 16) nw = 16;
-  while (nw > 1 && nw * MT > ODIC_SKINNY_LDS_KIB) --nw;      // per-wave split-K slabs: nw·MT KiB of LDS
-  if (nw < 1) nw = 1;
-  int kslice = ((p.K + nw - 1) / nw + 15) / 16 * 16;
-  dim3 grid((p.N + 15) / 16, 1, batch), block(64 * nw);
-  const size_t shmem = (size_t)(nw * MT * 256 + 2 * MT * 16) * sizeof(float);
-  const bool ln = p.ln_gamma != nullptr;
+  const int MT = (p.M + 15) / 16;
+  const int MS = (MT + MTW - 1) / MTW;
+  // K-slices of >= 64, KS·MS <= 16 waves, KS·MT KiB of LDS for the partial tiles <= ODIC_SKINNY_LDS_KIB
+  int KS = (p.K + 63) / 64;
+  if (KS > 16 / MS) KS = 16 / MS;
+  while (KS > 1 && KS * MT > ODIC_SKINNY_LDS_KIB) --KS;
+  if (KS < 1) KS = 1;
+  const int kslice = ((p.K + KS - 1) / KS + 15) / 16 * 16;
+  dim3 grid((p.N + 15) / 16, 1, batch), block(64 * KS * MS);
+  const size_t shmem = (size_t)(KS * MT * 256 + KS * MT * 32) * sizeof(float);
+  const bool fold = p.ln_colsum != nullptr;
   if (out_dtype == ODIC_BF16) {
-    if (ln) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MT, true, bf16_raw>), grid, block, shmem, stream, p, kslice);
-    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<MT, false, bf16_raw>), grid, block, shmem, stream, p, kslice);
+    if (fold) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, true, bf16_raw>), grid, block, shmem, stream, p, kslice, KS, MT);
+    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, false, bf16_raw>), grid, block, shmem, stream, p, kslice, KS, MT);
   } else {
-    if (ln) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MT, true, float>), grid, block, shmem, stream, p, kslice);
-    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<MT, false, float>), grid, block, shmem, stream, p, kslice);
+    if (fold) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, true, float>), grid, block, shmem, stream, p, kslice, KS, MT);
+    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, false, float>), grid, block, shmem, stream, p, kslice, KS, MT);
   }
 }
 
@@ -289,21 +298,18 @@ int odic_gemm_f32_launch(const odic_gemm_args* a, hipStream_t stream) {
   p.strideA = a->strideA; p.strideW = a->strideW; p.strideBias = a->strideBias;
   p.strideR = a->strideR; p.strideC = a->strideC;
   p.alpha = a->alpha; p.act = a->act; p.bias_axis = a->bias_axis;
-  p.ln_gamma = a->ln_gamma; p.ln_beta = a->ln_beta; p.ln_eps = a->ln_eps;
+  p.ln_colsum = a->ln_colsum; p.ln_eps = a->ln_eps;
   p.vec_ok = (a->lda % 4 == 0) && (a->ldw % 4 == 0) && (a->strideA % 4 == 0) && (a->strideW % 4 == 0) &&
              (((uintptr_t)a->A & 15) == 0) && (((uintptr_t)a->W & 15) == 0);
-  const bool want_ln = a->ln_gamma != nullptr;
-  if (want_ln && (!a->ln_beta || !(p.vec_ok && a->M <= 192 && a->K % 16 == 0 && a->K <= 1024 && a->batch == 1)))
-    return ODIC_EUNSUPPORTED;
-  if (p.vec_ok && a->M <= 192 && a->K % 16 == 0 && (a->N >= 64 || want_ln)) {
+  const bool want_ln = a->ln_colsum != nullptr;
+  const bool skinny_ok = p.vec_ok && a->M <= 192 && a->K % 16 == 0;
+  if (want_ln && !(skinny_ok && a->bias_axis == 0)) return ODIC_EUNSUPPORTED;
+  if (skinny_ok && (a->N >= 64 || want_ln)) {
     const int mt = (a->M + 15) / 16;
-    if (mt <= 1) launch_skinny<1>(p, a->out_dtype, a->batch, stream);
-    else if (mt <= 2) launch_skinny<2>(p, a->out_dtype, a->batch, stream);
-    else if (mt <= 3) launch_skinny<3>(p, a->out_dtype, a->batch, stream);
-    else if (mt <= 4) launch_skinny<4>(p, a->out_dtype, a->batch, stream);
-    else if (mt <= 6) launch_skinny<6>(p, a->out_dtype, a->batch, stream);
-    else if (mt <= 9) launch_skinny<9>(p, a->out_dtype, a->batch, stream);
-    else launch_skinny<12>(p, a->out_dtype, a->batch, stream);
+    // (MTW, UN): two rounds of UN·(1 + MTW) float4 per lane are in flight — 64 / 48 / 64 registers
+    if (mt <= 4) launch_skinny<1, 4>(p, a->out_dtype, a->batch, stream);        // one row tile per wave
+    else if (mt <= 8) launch_skinny<2, 2>(p, a->out_dtype, a->batch, stream);
+    else launch_skinny<3, 2>(p, a->out_dtype, a->batch, stream);
     return odic_launch_status();
   }
   dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM, a->batch);

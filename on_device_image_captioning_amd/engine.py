@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -148,6 +149,9 @@ class CaptionerEngine:
     def __init__(self, sd: SD, g: Geometry, device, precision: str = "fp32"):
         self.g, self.device, self.precision = g, device, precision
         self.cdt = _CDT[precision]
+        # decoder LayerNorms folded into the consuming skinny GEMM (10 fewer launches per step; see
+        # odic_gemm_args.ln_colsum).  ODIC_FOLD_LN=0 keeps the separate odic_layernorm launches.
+        self.fuse_ln = os.environ.get("ODIC_FOLD_LN", "1") == "1"
         d = g.d_model
         f32 = lambda k: _dev(sd[k], device, torch.float32)          # noqa: E731
         cat = lambda ks: torch.cat([f32(k) for k in ks], 0).contiguous()   # noqa: E731
@@ -187,6 +191,10 @@ class CaptionerEngine:
                 wo=f32(p + ".mha.out_linear.weight"), bo=f32(p + ".mha.out_linear.bias"),
                 f1w=f32(p + ".ff.linear_1.weight"), f1b=f32(p + ".ff.linear_1.bias"),
                 f2w=f32(p + ".ff.linear_2.weight"), f2b=f32(p + ".ff.linear_2.bias")))
+            w = self.dec[-1]
+            w["dyn_f"] = ops.fold_layernorm(w["dyn_w"], w["dyn_b"], w["n1w"], w["n1b"])
+            w["wq_f"] = ops.fold_layernorm(w["wq"], w["bq"], w["n2w"], w["n2b"])
+            w["f1_f"] = ops.fold_layernorm(w["f1w"], w["f1b"], w["n3w"], w["n3b"])
             kvw += [p + ".mha.Wk.weight", p + ".mha.Wv.weight"]
             kvb += [p + ".mha.Wk.bias", p + ".mha.Wv.bias"]
         self.kv_w32, self.kv_b = cat(kvw), cat(kvb)                 # [2·N_dec·d, d]
@@ -194,6 +202,7 @@ class CaptionerEngine:
         self.dr_w, self.dr_b = f32("dec_reduce_group.weight"), f32("dec_reduce_group.bias")
         self.drn_w, self.drn_b = f32("dec_reduce_norm.weight"), f32("dec_reduce_norm.bias")
         self.voc_w, self.voc_b = f32("vocab_linear.weight"), f32("vocab_linear.bias")
+        self.voc_f = ops.fold_layernorm(self.voc_w, self.voc_b, self.drn_w, self.drn_b)
         self.embed, self.pos_table = f32("out_embedder.embed.weight"), f32("pos_encoder.weight")
 
     # ------------------------------------------------------------------------------------------
@@ -294,32 +303,40 @@ class CaptionerEngine:
         d, L, N = g.d_model, g.N_dec, st.N
         ld = L * d
         ops.dec_embed(st.next_tok, self.embed, self.pos_table, st.pos, st.ycat, ld, N, d, math.sqrt(d))
+        fuse = self.fuse_ln
+        eps = 1e-5
+
+        def ln_gemm(x, ldx, nw, nb, W, b, folded, **kw):
+            """LayerNorm(x)·Wᵀ + b: one launch (LayerNorm folded into the product) or two."""
+            if fuse:
+                Wf, bf, cs = folded
+                return ops.gemm(x, Wf, bf, M=N, N=Wf.shape[0], K=d, lda=ldx, ldw=d, ldc=Wf.shape[0], ln_fold=(cs, eps), **kw)
+            return ops.gemm(ops.layernorm(x, nw, nb, M=N, C_=d, ldx=ldx), W, b, **kw)
+
         for i, w in enumerate(self.dec):
             c = st.caches[i]
             xin = st.ycat if i == 0 else st.ycat[:, (i - 1) * d:]
             xo = st.ycat[:, i * d:]
-            x2 = ops.layernorm(xin, w["n1w"], w["n1b"], M=N, C_=d, ldx=ld)
-            lin = ops.gemm(x2, w["dyn_w"], w["dyn_b"])                                       # [N,5d]
+            lin = ln_gemm(xin, ld, w["n1w"], w["n1b"], w["dyn_w"], w["dyn_b"], w["dyn_f"])               # [N,5d]
             ops.dynexp_step(lin, 5 * d, w["qexp"], w["bexp"], c["cond"], c["key"], c["va"], c["vb"], c["afull"],
                             c["bfull"], c["qk"], st.anc, st.row_valid, st.pos, xin, ld, xo, ld, st.dyn_scratch, N, st.T, d,
                             g.num_exp_dec)
-            x2 = ops.layernorm(xo, w["n2w"], w["n2b"], M=N, C_=d, ldx=ld)
-            q = ops.gemm(x2, w["wq"], w["bq"])
+            q = ln_gemm(xo, ld, w["n2w"], w["n2b"], w["wq"], w["bq"], w["wq_f"])
             att = torch.empty(N, d, dtype=torch.float32, device=self.device)
             ops.cross_attn_step(q, d, st.kv, st.kv.shape[2], 2 * i * d, (2 * i + 1) * d, st.enc_len,
                                 st.row_valid, att, d, N, st.n_img, st.S, d, g.num_heads)
             ops.gemm(att, w["wo"], w["bo"], residual=xo, out=xo, M=N, N=d, K=d, lda=d, ldw=d, ldr=ld, ldc=ld)
-            x2 = ops.layernorm(xo, w["n3w"], w["n3b"], M=N, C_=d, ldx=ld)
-            h = ops.gemm(x2, w["f1w"], w["f1b"], act=ops.ACT_RELU)
+            h = ln_gemm(xo, ld, w["n3w"], w["n3b"], w["f1w"], w["f1b"], w["f1_f"], act=ops.ACT_RELU)
             ops.gemm(h, w["f2w"], w["f2b"], residual=xo, out=xo, M=N, N=d, K=g.ff, lda=g.ff, ldw=g.ff, ldr=ld,
                      ldc=ld)
         pre = torch.empty(N, d, dtype=torch.float32, device=self.device)
         ops.gemm(st.ycat, self.dr_w, self.dr_b, residual=st.ycat[:, (L - 1) * d:], out=pre, M=N, N=d, K=ld, lda=ld,
                  ldw=ld, ldr=ld, ldc=d)
-        # (odic_gemm can fuse these LayerNorms into its A-operand load — `ln=` — but with 32-160 blocks
-        #  each recomputing the row moments that measured slower than the separate 4 µs launch)
-        zf = ops.layernorm(pre, self.drn_w, self.drn_b)
-        ops.gemm(zf, self.voc_w, self.voc_b, out=st.logits)
+        if fuse:
+            ops.gemm(pre, self.voc_f[0], self.voc_f[1], out=st.logits, M=N, N=g.vocab_size, K=d, lda=d, ldw=d,
+                     ldc=g.vocab_size, ln_fold=(self.voc_f[2], eps))
+        else:
+            ops.gemm(ops.layernorm(pre, self.drn_w, self.drn_b), self.voc_w, self.voc_b, out=st.logits)
 
     def beam_step(self, st: DecodeState, eos_idx: int) -> None:
         """One full search step: decoder → log-softmax/top-k → on-device beam bookkeeping."""

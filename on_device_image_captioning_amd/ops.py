@@ -134,11 +134,11 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
          M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None,
          lda: Optional[int] = None, ldw: Optional[int] = None, ldr: Optional[int] = None,
          ldc: Optional[int] = None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideBias: int = 0,
-         strideR: int = 0, strideC: int = 0, ln: Optional[tuple] = None) -> torch.Tensor:
+         strideR: int = 0, strideC: int = 0, ln_fold: Optional[tuple] = None) -> torch.Tensor:
     """out = act(alpha·A·Wᵀ + bias) + residual.  With no explicit dims, A is [..., K] (flattened to
     [M,K]) and W is [N,K], both contiguous.  Explicit dims / leading dimensions / batch strides allow
-    strided sub-matrices (elements).  ln = (gamma, beta, eps): LayerNorm fused on the rows of A (fp32
-    skinny-M path only)."""
+    strided sub-matrices (elements).  ln_fold = (colsum, eps): W and bias come from fold_layernorm() and
+    the rows of A are LayerNorm-ed inside the product (fp32 skinny-M path only)."""
     _need_cuda(A, W, bias, residual, out)
     if A.dtype != W.dtype:
         raise RuntimeError("A and W must share a dtype")
@@ -167,7 +167,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
     a = _hip.GemmArgs(_p(A), _p(W), _p(bias), _p(residual), _p(out), M, N, K, lda, ldw, ldr or 0, ldc, batch,
                       strideA, strideW, strideBias, strideR, strideC, alpha, act, bias_axis,
                       dtype_code(A.dtype), dtype_code(out.dtype), -1,
-                      _p(ln[0]) if ln else None, _p(ln[1]) if ln else None, float(ln[2]) if ln else 0.0)
+                      _p(ln_fold[0]) if ln_fold else None, float(ln_fold[1]) if ln_fold else 0.0)
     if A.dtype == torch.bfloat16:
         key = (M, N, K, batch, out.dtype, act, residual is not None)
         cfg = _TILE_CHOICE.get(key)
@@ -184,6 +184,15 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
                 f"{M}x{N}x{K}" + (f"x{batch}" if batch > 1 else "")):
         _hip.check(_hip.load().odic_gemm(C.byref(a), _stream()), "odic_gemm")
     return out
+
+
+def fold_layernorm(W: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """Weight-pack-time half of odic_gemm's folded LayerNorm: (W·diag(gamma), bias + W·beta, row sums of
+    W·diag(gamma)), all fp32, computed in fp64.  LayerNorm(a)·Wᵀ + bias = rstd·(a·W'ᵀ − mean·colsum) + bias'."""
+    W64 = W.double()
+    Wg = W64 * gamma.double()[None, :]
+    b2 = W64 @ beta.double() + (bias.double() if bias is not None else 0.0)
+    return Wg.float().contiguous(), b2.float().contiguous(), Wg.sum(1).float().contiguous()
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, eps: float = 1e-5,

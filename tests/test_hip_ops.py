@@ -79,18 +79,37 @@ def test_gemm_f32_row_bias_strided_batched(ops):
     assert torch.all(got[:, :, N:] == 7.0), "padding columns must stay untouched"
 
 
-def test_gemm_f32_fused_layernorm(ops):
-    # LayerNorm(A)·Wᵀ with A a strided slice of a wider buffer (the decoder's residual-stream layout)
-    M, N, K, lda = 48, 200, 512, 1536
+@pytest.mark.parametrize("M,N,K,act", [(48, 200, 512, 0), (48, 2048, 512, 2), (144, 512, 512, 0), (17, 100, 64, 0),
+                                       (100, 1000, 512, 0)])
+def test_gemm_f32_folded_layernorm(ops, M, N, K, act):
+    # LayerNorm(A)·Wᵀ + b with A a strided slice of a wider buffer (the decoder's residual-stream layout),
+    # LayerNorm folded into the product: W·diag(gamma), bias + W·beta, row sums (ops.fold_layernorm)
+    lda = 3 * K
     buf, Wt, b = rnd(M, lda, seed=1, scale=2.0) + 0.3, rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
     g, be = 1 + 0.1 * rnd(K, seed=4), 0.1 * rnd(K, seed=5)
-    A = buf[:, 512:1024]
+    A = buf[:, K:2 * K]
     want = torch.nn.functional.layer_norm(A.double(), (K,), g.double(), be.double(), 1e-5) @ Wt.double().T + b.double()
+    if act == 2:
+        want = torch.relu(want)
+    Wf, bf, cs = ops.fold_layernorm(dev(Wt), dev(b), dev(g), dev(be))
     dbuf = dev(buf)
-    got = ops.gemm(dbuf[:, 512:], dev(Wt), dev(b), M=M, N=N, K=K, lda=lda, ldw=K, ldc=N, ln=(dev(g), dev(be), 1e-5))
-    assert_close(got, want, 3e-5, "fused LN gemm")
+    got = ops.gemm(dbuf[:, K:], Wf, bf, M=M, N=N, K=K, lda=lda, ldw=K, ldc=N, act=act, ln_fold=(cs, 1e-5))
+    assert_close(got, want, 3e-5, "folded LN gemm")
+
+
+def test_gemm_f32_folded_layernorm_rejects_wide_M(ops):
     with pytest.raises(RuntimeError):          # not available outside the skinny fp32 path
-        ops.gemm(dev(rnd(400, 64, seed=1)), dev(rnd(64, 64, seed=2)), ln=(dev(rnd(64)), dev(rnd(64)), 1e-5))
+        Wf, bf, cs = ops.fold_layernorm(dev(rnd(64, 64, seed=2)), None, dev(rnd(64)), dev(rnd(64)))
+        ops.gemm(dev(rnd(400, 64, seed=1)), Wf, bf, ln_fold=(cs, 1e-5))
+
+
+@pytest.mark.parametrize("M,N,K", [(48, 512, 2048), (48, 512, 1536), (96, 512, 512), (150, 10000, 512), (192, 64, 4096)])
+def test_gemm_f32_skinny_wave_splits(ops, M, N, K):
+    # K-slices x row-tile groups across the waves of a block, with residual + relu epilogue
+    A, Wt, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
+    want = torch.relu(A.double() @ Wt.double().T + b.double()) + r.double()
+    got = ops.gemm(dev(A), dev(Wt), dev(b), dev(r), act=2)
+    assert_close(got, want, 2e-5, "gemm_f32 skinny")
 
 
 # ------------------------------------------------------------------------------------------ GEMM bf16
