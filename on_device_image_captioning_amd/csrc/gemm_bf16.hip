@@ -223,6 +223,230 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
   }
 }
 
+// =================================================================================================
+// 256 x 256 x 64 tile, one block of 8 waves per CU, four phases per K-tile (config 12).
+//
+// The generic kernel above fills LDS at ~half of what a CU can take from L2 and keeps the matrix pipe
+// ~30 % busy: per K-tile it is one wait + one barrier + a compiler-scheduled blob.  This one follows
+// the phase structure of cdna_hip_programming.md §5 ("256² 8-phase"): the 256 x 256 accumulator is
+// cut into four 128 x 128 QUADRANTS (A half i x W half j); a phase = every wave's 64 x 32 patch of
+// one quadrant over the whole K-tile (16 MFMAs) and the LDS-DMA of ONE 16-KiB half-tile (2 per wave):
+//
+//   phase  quadrant   LDS fragment reads           stages (dest. = LDS parity of that K-tile)
+//     1    (A0, W0)   W0: 4, A0: 8 ds_read_b128    A1 of K-tile c+1
+//     2    (A0, W1)   W1: 4 (A0 stays in regs)     W0 of K-tile c+1
+//     3    (A1, W1)   A1: 8 (W1 stays)             A0 of K-tile c+2   (A0 of c: last read in phase 1)
+//     4    (A1, W0)   W0: 4 (A1 stays)             W1 of K-tile c+2   (W1 of c: last read in phase 2)
+//
+// so every half-tile buffer is restaged two phases after its last read (WAR) and is read no earlier
+// than the phase after the counted wait + barrier that retires it (RAW): the
+// only vmcnt is in phase 4, vmcnt(4) = the two half-tiles of K-tile c+2 just issued stay in flight,
+// everything of K-tile c+1 has landed.  128 KiB of LDS (2 parities x 4 halves), 128 accumulator
+// registers per lane, operands swapped / W rows permuted exactly as in the generic kernel.
+// Requires K % 128 == 0 (K-tiles are processed in pairs so that LDS parities are compile-time).
+// =================================================================================================
+template <typename OutT>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256sq_kernel(Params p) {
+  constexpr int HALF = 128 * 128;               // bytes of one half-tile: 128 rows x 64 bf16
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // [parity 2][A0, A1, W0, W1][128][128 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  int tm, tn;
+  {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int xm = xcd / p.pn, xn = xcd - xm * p.pn;
+    const int r0 = xm * p.tiles_m / p.pm, r1 = (xm + 1) * p.tiles_m / p.pm;
+    const int c0 = xn * p.tiles_n / p.pn, c1 = (xn + 1) * p.tiles_n / p.pn;
+    const int w = c1 - c0;
+    if (idx >= (r1 - r0) * w) return;
+    const int lr = idx / w;
+    tm = r0 + lr; tn = c0 + (idx - lr * w);
+  }
+  const int m0 = tm * 256, n0 = tn * 256;
+  const long bz = blockIdx.z;
+  const bf16_raw* A = p.A + bz * p.strideA;
+  const bf16_raw* W = p.W + bz * p.strideW;
+
+  // ---- LDS-DMA sources: a half-tile is 16 pieces of 1 KiB (8 rows x 128 B); wave w moves pieces 2w, 2w+1
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;          // swizzle: chunk ^ (row & 7)
+  const bf16_raw* src[4][2];                                       // [A0, A1, W0, W1][piece]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 8 + srow;                     // row inside the half-tile
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      src[h][i] = A + (long)min(m0 + h * 128 + row, p.M - 1) * p.lda + schunk * 8;
+      src[2 + h][i] = W + (long)min(n0 + h * 128 + wperm(row), p.N - 1) * p.ldw + schunk * 8;
+    }
+  }
+  auto stage = [&](int parity, int h, int kt) {
+    char* dst = lds + (parity * 4 + h) * HALF + wave * 2048;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[h][0] + (long)kt * 64), (lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[h][1] + (long)kt * 64), (lptr_t)(dst + 1024), 16, 0, 0);
+  };
+
+  f32x4_t acc[2][2][4][2];                                         // [A half][W half][mi][ni]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[i][j][mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / 64;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int a_off = (wr * 64 + frow) * 128, w_off = (wc * 32 + frow) * 128;
+  const int c0 = ((0 + fq) ^ (frow & 7)) << 4, c1 = ((4 + fq) ^ (frow & 7)) << 4;   // kk = 0 / 1 chunks
+
+  bf16x8_t af[4][2], wf[2][2];                                     // [mi or ni][kk]
+  auto read_a = [&](int parity, int h) {
+    const char* b = lds + (parity * 4 + h) * HALF + a_off;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      af[mi][0] = *(const bf16x8_t*)(b + mi * 16 * 128 + c0);
+      af[mi][1] = *(const bf16x8_t*)(b + mi * 16 * 128 + c1);
+    }
+  };
+  auto read_w = [&](int parity, int h) {
+    const char* b = lds + (parity * 4 + 2 + h) * HALF + w_off;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      wf[ni][0] = *(const bf16x8_t*)(b + ni * 16 * 128 + c0);
+      wf[ni][1] = *(const bf16x8_t*)(b + ni * 16 * 128 + c1);
+    }
+  };
+  auto mma = [&](int i, int j) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[i][j][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][kk], af[mi][kk], acc[i][j][mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // prologue: all of K-tile 0, plus A0 / W1 of K-tile 1 (its A1 / W0 follow in phases 1 and 2)
+  stage(0, 0, 0); stage(0, 2, 0); stage(0, 3, 0); stage(0, 1, 0);
+  if (nk > 1) {
+    stage(1, 0, 1); stage(1, 3, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+
+  // The two wave rows run half a phase apart (one extra barrier for row 1 here, one for row 0 after the
+  // loop): a SIMD holds one wave of each row, so while one of them issues its 16 MFMAs the other is in
+  // its load segment (fragment reads, LDS-DMA issue, counted wait) — the matrix pipe never waits for LDS.
+  // Every segment ends in a block-wide barrier.  Hazards with the half-phase skew: a buffer is restaged
+  // two phases (four segments) after its last read, the later row finishes that read two segments after
+  // the earlier one started it; a retired K-tile is first read two segments after the earlier row's wait,
+  // i.e. one segment after the later row's wait + barrier.
+  auto ktile = [&](int c, int parity) {           // parity is a literal at both call sites
+    // ---- phase 1: quadrant (A0, W0)
+    read_w(parity, 0); read_a(parity, 0);
+    if (c + 1 < nk) stage(parity ^ 1, 1, c + 1);
+    __builtin_amdgcn_s_barrier();
+    mma(0, 0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: quadrant (A0, W1)
+    read_w(parity, 1);
+    if (c + 1 < nk) stage(parity ^ 1, 2, c + 1);
+    __builtin_amdgcn_s_barrier();
+    mma(0, 1);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: quadrant (A1, W1)
+    read_a(parity, 1);
+    if (c + 2 < nk) stage(parity, 0, c + 2);
+    __builtin_amdgcn_s_barrier();
+    mma(1, 1);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 4: quadrant (A1, W0); the counted wait retires every half-tile of K-tile c+1
+    read_w(parity, 0);
+    if (c + 2 < nk) {
+      stage(parity, 3, c + 2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    mma(1, 0);
+    __builtin_amdgcn_s_barrier();
+  };
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+  for (int c = 0; c < nk; c += 2) {
+    ktile(c, 0);
+    ktile(c + 1, 1);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue (same lane → 8 adjacent output columns mapping as the generic kernel)
+  const float* bias = p.bias ? p.bias + bz * p.strideBias : nullptr;
+  const float* resid = p.residual ? p.residual + bz * p.strideR : nullptr;
+  OutT* out = (OutT*)p.out + bz * p.strideC;
+  const bool ld_ok = ((p.ldc & 7) == 0) && (!resid || (p.ldr & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + j * 128 + wc * 32 + fq * 8;
+    if (col >= p.N) continue;
+    float bc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bc[e] = (bias && !p.bias_axis && col + e < p.N) ? bias[col + e] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int row = m0 + i * 128 + wr * 64 + mi * 16 + frow;
+        if (row >= p.M) continue;
+        const float brow = (bias && p.bias_axis) ? bias[row] : 0.f;
+        f32x4_t v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f32x4_t pre = acc[i][j][mi][h] * p.alpha + f32x4_t{bc[4 * h], bc[4 * h + 1], bc[4 * h + 2], bc[4 * h + 3]} + brow;
+          if (p.act == ODIC_ACT_GELU) {
+            pre = gelu_poly4(pre);
+          } else if (p.act != ODIC_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pre[e] = apply_act<true>(pre[e], p.act);
+          }
+          v[h] = pre;
+        }
+        if (ld_ok && col + 7 < p.N) {
+          if (resid) {
+            const f32x4_t* rp = (const f32x4_t*)(resid + (long)row * p.ldr + col);
+            v[0] += rp[0]; v[1] += rp[1];
+          }
+          OutT* dst = out + (long)row * p.ldc + col;
+          if constexpr (sizeof(OutT) == 4) {
+            ((f32x4_t*)dst)[0] = v[0]; ((f32x4_t*)dst)[1] = v[1];
+          } else {
+            bf16x8_t pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pk[e] = (short)f32_to_bf16(v[0][e]); pk[4 + e] = (short)f32_to_bf16(v[1][e]); }
+            *(bf16x8_t*)dst = pk;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (col + e < p.N) {
+              float x = v[e >> 2][e & 3];
+              if (resid) x += resid[(long)row * p.ldr + col + e];
+              store_from_f32<OutT>(out + (long)row * p.ldc + col + e, x);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK = 64>
 int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
   constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
@@ -252,6 +476,36 @@ int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
       (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
       done = true;
     }
+  }
+  if (out_dtype == ODIC_BF16) hipLaunchKernelGGL(kb, grid, block, SHMEM, stream, p);
+  else hipLaunchKernelGGL(kf, grid, block, SHMEM, stream, p);
+  return odic_launch_status();
+}
+
+int launch_256sq(Params& p, int out_dtype, int batch, hipStream_t stream) {
+  constexpr int SHMEM = 128 * 1024;
+  if (p.K % 128 != 0) return ODIC_EINVAL;
+  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
+  int pn = 1;
+  while (pn < 8 && pn * 2 <= p.tiles_n && (double)p.N / pn * p.K * 2.0 > 2.5 * 1024 * 1024) pn *= 2;
+  int pm = 8 / pn;
+  while (pm > p.tiles_m && pm > 1) { pm /= 2; pn *= 2; }
+  if (pn > p.tiles_n) { pn = 1; pm = 8; while (pm > p.tiles_m && pm > 1) pm /= 2; pn = 8 / pm; }
+  p.pm = pm; p.pn = pn;
+  int max_rect = 0;
+  for (int xm = 0; xm < pm; ++xm)
+    for (int xn = 0; xn < pn; ++xn) {
+      const int r = ((xm + 1) * p.tiles_m / pm - xm * p.tiles_m / pm) * ((xn + 1) * p.tiles_n / pn - xn * p.tiles_n / pn);
+      if (r > max_rect) max_rect = r;
+    }
+  dim3 grid(8 * max_rect, 1, batch), block(512);
+  auto kb = gemm_bf16_256sq_kernel<bf16_raw>;
+  auto kf = gemm_bf16_256sq_kernel<float>;
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+    (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+    done = true;
   }
   if (out_dtype == ODIC_BF16) hipLaunchKernelGGL(kb, grid, block, SHMEM, stream, p);
   else hipLaunchKernelGGL(kf, grid, block, SHMEM, stream, p);
@@ -303,6 +557,7 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     case 9: return launch_cfg<2, 4, 8, 4, 2, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32 (64 KiB)
     case 10: return launch_cfg<4, 2, 4, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32, 3 stages (72 KiB)
     case 11: return launch_cfg<2, 4, 8, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32, 3 stages (96 KiB)
+    case 12: return launch_256sq(p, a->out_dtype, a->batch, stream);                 // 256 x 256 x 64, 4 phases per K-tile (128 KiB)
     default: return ODIC_EINVAL;
   }
 }

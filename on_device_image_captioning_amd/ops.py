@@ -7,6 +7,7 @@ falls back — a non-CUDA tensor or a missing library raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -86,7 +87,7 @@ def dtype_code(dt: torch.dtype) -> int:
 # fastest; later calls (including the captured ones) reuse the choice.
 _TILE_CHOICE: dict = {}
 _TUNING = False
-_TILE_CANDIDATES = (0, 1, 2, 7, 10)
+_TILE_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_TILE_CANDIDATES", "0,1,2,7,10").split(","))
 
 
 class autotune:

@@ -332,6 +332,31 @@ def test_dynexp_step_matches_full_recompute(ops):
     assert_close(got, want, 5e-5, "dynexp_step")
 
 
+def test_gemm_bf16_256sq_phase_pipeline(ops):
+    """Config 12 (256x256 tile, four phases per K-tile, counted LDS-DMA waits): ragged M/N, 2..24 K-tiles,
+    every epilogue feature, and run-to-run identical results (a pipeline race shows up as flicker)."""
+    from on_device_image_captioning_amd import _hip
+    lib = _hip.load()
+    try:
+        lib.odic_gemm_bf16_force_config(12)
+        for (M, N, K) in ((300, 328, 128), (517, 260, 384), (1024, 768, 768), (2304, 1536, 1536), (700, 3072, 256)):
+            A, Wt = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=0.05).bfloat16()
+            b, r = rnd(N, seed=3), rnd(M, N, seed=4)
+            want = torch.relu(0.5 * (A.double() @ Wt.double().T) + b.double()) + r.double()
+            dA, dW, db, dr = dev(A), dev(Wt), dev(b), dev(r)
+            got = ops.gemm(dA, dW, db, dr, act=2, alpha=0.5, out_dtype=torch.float32)
+            assert_close(got, want, 2e-4, f"cfg12 {M}x{N}x{K}")
+            for _ in range(20):
+                again = ops.gemm(dA, dW, db, dr, act=2, alpha=0.5, out_dtype=torch.float32)
+                assert torch.equal(again, got), f"cfg12 {M}x{N}x{K}: results differ between launches"
+            got16 = ops.gemm(dA, dW, db, act=1, out_dtype=torch.bfloat16)
+            assert_close(got16, torch.nn.functional.gelu(A.double() @ Wt.double().T + b.double()), 6e-3, "cfg12 gelu→bf16")
+        with pytest.raises(RuntimeError):                 # K-tiles are consumed in pairs
+            ops.gemm(dev(rnd(256, 192, seed=1)).bfloat16(), dev(rnd(256, 192, seed=2)).bfloat16())
+    finally:
+        lib.odic_gemm_bf16_force_config(-1)
+
+
 @pytest.mark.parametrize("cfg", list(range(12)))
 def test_gemm_bf16_every_tile_config(ops, cfg):
     """Each tile / pipeline-depth / BK instantiation against fp64 on ragged shapes (M, N not multiples

@@ -31,8 +31,12 @@ for M, N, K, kind in shapes:
     cells = []
     for cfg in CFGS:
         lib.odic_gemm_bf16_force_config(cfg)
-        for _ in range(3):
-            ops.gemm(A, W, bias, res, out=out, act=act)
+        try:
+            for _ in range(3):
+                ops.gemm(A, W, bias, res, out=out, act=act)
+        except RuntimeError:
+            cells.append("     n/a        ")
+            continue
         torch.cuda.synchronize()
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 20
