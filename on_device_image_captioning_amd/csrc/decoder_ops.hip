@@ -245,75 +245,121 @@ __global__ __launch_bounds__(128) void dynexp_accum_kernel(DynParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Cross attention: one wave per (sequence, head).  kv: [n_img, S, ldkv], K at koff, V at voff.
-//   scores : dk/16 lanes per key (16 floats each), 64/(dk/16) keys per sweep, xor-shuffle reduce
-//   softmax: lanes stride over S
-//   P·V    : lane = channel of the head, coalesced dk·4-byte rows, 8 keys in flight
+// Cross attention: one block (4 waves) per (image, head, chunk of NB beams).  The k beams of an image
+// attend to the SAME K/V, so every K/V element is loaded once per block and used for all NB queries
+// (the one-wave-per-sequence form re-read 72 KB per beam and ran ~27 dependent load rounds):
+//   scores : dk/16 lanes per key (16 floats each); the 4 waves sweep 4·64/(dk/16) keys at a time, all
+//            sweeps of a wave in flight together; xor-shuffle reduce; NB dot products per loaded key
+//   softmax: wave b normalises beam b (lanes stride over S), base e as the reference
+//   P·V    : thread = (channel of the head, key group); coalesced dk·4-byte rows, 12 keys in flight,
+//            NB accumulators; key groups combined through LDS.
+// kv: [n_img, S, ldkv], K at koff, V at voff.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void cross_attn_step_kernel(const float* __restrict__ q, long ldq,
-                                                             const float* __restrict__ kv, long ldkv, int koff,
-                                                             int voff, const int* __restrict__ enc_len,
-                                                             const int* __restrict__ row_valid,
-                                                             float* __restrict__ out, long ldo, int beams, int S,
-                                                             int d, int heads) {
-  extern __shared__ float sc[];          // [S]
-  const int n = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-  const int img = n / beams;
+template <int NB>
+__global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __restrict__ q, long ldq,
+                                                              const float* __restrict__ kv, long ldkv, int koff,
+                                                              int voff, const int* __restrict__ enc_len,
+                                                              const int* __restrict__ row_valid,
+                                                              float* __restrict__ out, long ldo, int beams, int S,
+                                                              int d, int heads) {
+  extern __shared__ float smem[];        // sc[NB][S] | red[256 / dk][NB][dk] | lsum[NB]
+  const int img = blockIdx.x, h = blockIdx.y, b0 = blockIdx.z * NB;
+  const int nb = min(NB, beams - b0);    // beams handled here
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int dk = d / heads;
   const int lpk = dk >> 4;               // lanes per key (1, 2 or 4)
-  const int kps = 64 / lpk;              // keys per sweep
+  const int kps = 64 / lpk;              // keys per wave-sweep
   const int len = enc_len[img];
-  const int valid = row_valid[n];
   const float inv = rsqrtf((float)dk);
   const float* kvb = kv + (long)img * S * ldkv;
   const int part = lane % lpk, kslot = lane / lpk;
+  float* sc = smem;
+  float* red = smem + NB * S;
+  float* lsum = red + 256 * NB;
+  const long n0 = (long)img * beams + b0;   // first sequence row of this block
 
-  float4 qv[4];
-  {
-    const float* qp = q + (long)n * ldq + h * dk + part * 16;
+  float4 qv[NB][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qv[i] = *(const float4*)(qp + 4 * i);
+  for (int b = 0; b < NB; ++b) {
+    const float* qp = q + (n0 + min(b, nb - 1)) * ldq + h * dk + part * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qv[b][i] = *(const float4*)(qp + 4 * i);
   }
-  for (int s0 = 0; s0 < S; s0 += kps) {
-    const int s = s0 + kslot;
-    float acc = 0.f;
-    if (s < S) {
+  int valid[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) valid[b] = row_valid[n0 + min(b, nb - 1)];
+
+  // ---- scores: wave w takes sweeps w, w+4, ...; up to 3 sweeps of K loads in flight
+  const int nsweep = (S + kps - 1) / kps;
+  for (int sw0 = wave; sw0 < nsweep; sw0 += 12) {
+    float4 k4[3][4];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int s = min((sw0 + 4 * u) * kps + kslot, S - 1);
       const float* kr = kvb + (long)s * ldkv + koff + h * dk + part * 16;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 k4 = *(const float4*)(kr + 4 * i);
-        acc = fmaf(qv[i].x, k4.x, acc); acc = fmaf(qv[i].y, k4.y, acc);
-        acc = fmaf(qv[i].z, k4.z, acc); acc = fmaf(qv[i].w, k4.w, acc);
-      }
+      for (int i = 0; i < 4; ++i) k4[u][i] = *(const float4*)(kr + 4 * i);
     }
-    for (int o = 1; o < lpk; o <<= 1) acc += __shfl_xor(acc, o, 64);
-    if (part == 0 && s < S) {
-      float v = acc * inv;
-      if (!valid || s >= len) v = -1e4f;      // masked_fill(mask == 0, -1e4), layers.py:286
-      sc[s] = v;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int sw = sw0 + 4 * u;
+      const int s = sw * kps + kslot;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc = fmaf(qv[b][i].x, k4[u][i].x, acc); acc = fmaf(qv[b][i].y, k4[u][i].y, acc);
+          acc = fmaf(qv[b][i].z, k4[u][i].z, acc); acc = fmaf(qv[b][i].w, k4[u][i].w, acc);
+        }
+        for (int o = 1; o < lpk; o <<= 1) acc += __shfl_xor(acc, o, 64);
+        if (part == 0 && sw < nsweep && s < S) {
+          float v = acc * inv;
+          if (!valid[b] || s >= len) v = -1e4f;      // masked_fill(mask == 0, -1e4), layers.py:286
+          sc[b * S + s] = v;
+        }
+      }
     }
   }
   __syncthreads();
-  float m = -INFINITY;
-  for (int s = lane; s < S; s += 64) m = fmaxf(m, sc[s]);
-  m = wave_max(m);
-  float l = 0.f;
-  for (int s = lane; s < S; s += 64) { const float e = expf(sc[s] - m); sc[s] = e; l += e; }
-  l = wave_sum(l);
+  // ---- softmax: wave b → beam b, b + 4, ...
+  for (int b = wave; b < nb; b += 4) {
+    float m = -INFINITY;
+    for (int s = lane; s < S; s += 64) m = fmaxf(m, sc[b * S + s]);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int s = lane; s < S; s += 64) { const float e = expf(sc[b * S + s] - m); sc[b * S + s] = e; l += e; }
+    l = wave_sum(l);
+    if (lane == 0) lsum[b] = l;
+  }
   __syncthreads();
-  if (lane < dk) {
-    const float* vp = kvb + voff + h * dk + lane;
-    float acc = 0.f;
-    int s = 0;
-    for (; s + 8 <= S; s += 8) {
-      float v[8];
+  // ---- P·V: thread = (channel c, key group g); groups take keys g, g + ng, ...
+  const int c = tid % dk, g = tid / dk, ng = 256 / dk;
+  float acc[NB];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = vp[(long)(s + i) * ldkv];
+  for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+  const float* vp = kvb + voff + h * dk + c;
+  for (int s0 = g; s0 < S; s0 += 12 * ng) {
+    float v[12];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc = fmaf(sc[s + i], v[i], acc);
+    for (int i = 0; i < 12; ++i) v[i] = vp[(long)min(s0 + i * ng, S - 1) * ldkv];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int s = s0 + i * ng;
+      if (s < S) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = fmaf(sc[(b < nb ? b : 0) * S + s], v[i], acc[b]);
+      }
     }
-    for (; s < S; ++s) acc = fmaf(sc[s], vp[(long)s * ldkv], acc);
-    out[(long)n * ldo + h * dk + lane] = acc / l;
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) red[(g * NB + b) * dk + c] = acc[b];
+  __syncthreads();
+  for (int e = tid; e < nb * dk; e += 256) {
+    const int b = e / dk, cc = e - b * dk;
+    float v = 0.f;
+    for (int gg = 0; gg < ng; ++gg) v += red[(gg * NB + b) * dk + cc];
+    out[(n0 + b) * ldo + h * dk + cc] = v / lsum[b];
   }
 }
 
@@ -556,10 +602,20 @@ extern "C" int odic_cross_attn_step(const float* q, int64_t ldq, const float* kv
   const int dk = d / heads;
   if (dk != 16 && dk != 32 && dk != 64) return ODIC_EUNSUPPORTED;
   if ((ldq & 3) || (ldkv & 3) || (koff & 3) || ((uintptr_t)q & 15) || ((uintptr_t)kv & 15)) return ODIC_EINVAL;
-  if (S > 8192) return ODIC_EINVAL;
-  hipLaunchKernelGGL(cross_attn_step_kernel, dim3(N, heads), dim3(64), (size_t)S * sizeof(float),
-                     (hipStream_t)stream, q, (long)ldq, kv, (long)ldkv, koff, voff, enc_len, row_valid, out,
-                     (long)ldo, N / n_img, S, d, heads);
+  if (S > 2048) return ODIC_EINVAL;       // score rows of up to 5 beams live in LDS
+  const int beams = N / n_img;
+  hipStream_t st = (hipStream_t)stream;
+#define ODIC_XATTN(NB)                                                                                              \
+  hipLaunchKernelGGL(cross_attn_step_kernel<NB>, dim3(n_img, heads, (beams + NB - 1) / NB), dim3(256),              \
+                     (size_t)(NB * S + 256 * NB + NB) * sizeof(float), st, q, (long)ldq, kv, (long)ldkv, koff, voff,  \
+                     enc_len, row_valid, out, (long)ldo, beams, S, d, heads)
+  if (heads > 65535) return ODIC_EINVAL;
+  if (beams == 1) ODIC_XATTN(1);
+  else if (beams == 2) ODIC_XATTN(2);
+  else if (beams == 3) ODIC_XATTN(3);
+  else if (beams == 5 || beams > 8) ODIC_XATTN(5);
+  else ODIC_XATTN(4);
+#undef ODIC_XATTN
   return odic_launch_status();
 }
 

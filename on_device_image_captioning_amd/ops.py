@@ -87,7 +87,7 @@ def dtype_code(dt: torch.dtype) -> int:
 # fastest; later calls (including the captured ones) reuse the choice.
 _TILE_CHOICE: dict = {}
 _TUNING = False
-_TILE_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_TILE_CANDIDATES", "0,1,2,7,10").split(","))
+_TILE_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_TILE_CANDIDATES", "0,1,7,10").split(","))
 
 
 class autotune:

@@ -269,14 +269,17 @@ def test_logsoftmax_topk(ops):
     assert_close(tv, wv, 2e-6, "topk values")
 
 
-def test_cross_attn_step(ops):
-    n_img, beams, S, d, heads = 3, 2, 20, 128, 4
+@pytest.mark.parametrize("beams,S,d,heads", [(2, 20, 128, 4), (1, 144, 512, 8), (3, 144, 512, 8), (5, 144, 512, 8),
+                                             (7, 50, 128, 8), (11, 33, 64, 4)])
+def test_cross_attn_step(ops, beams, S, d, heads):
+    n_img = 3
     N = n_img * beams
     q = rnd(N, d, seed=1)
     kv = rnd(n_img, S, 3 * d, seed=2)          # K at col 16.. is not contiguous with V on purpose
     koff, voff = d, 2 * d
-    lens = torch.tensor([20, 11, 16], dtype=torch.int32)
-    valid = torch.tensor([1, 1, 1, 0, 1, 1], dtype=torch.int32)
+    lens = torch.tensor([S, max(1, S // 2 + 1), max(1, S - 4)], dtype=torch.int32)
+    valid = torch.ones(N, dtype=torch.int32)
+    valid[min(3, N - 1)] = 0
     out = torch.empty(N, d, device="cuda")
     ops.cross_attn_step(dev(q), d, dev(kv), 3 * d, koff, voff, dev(lens), dev(valid), out, d, N, n_img, S, d, heads)
     dk = d // heads
