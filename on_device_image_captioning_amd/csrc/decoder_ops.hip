@@ -129,6 +129,7 @@ __global__ __launch_bounds__(512) void dynexp_scores_kernel(DynParams p) {
       a = p.cond_c + ((long)j * NT + slot[j]) * d; b = key_t;
     }
     float s = 0.f;
+#pragma unroll 8
     for (int c = gl * 4; c < d; c += 64) {
       const float4 av = *(const float4*)(a + c);
       const float4 bv = *(const float4*)(b + c);
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(128) void dynexp_accum_kernel(DynParams p) {
   float fa[EE], fb[EE];
 #pragma unroll
   for (int e = 0; e < EE; ++e) { fa[e] = 0.f; fb[e] = 0.f; }
+#pragma unroll 4
   for (int j = 0; j <= t; ++j) {
     const long o = ((long)j * NT + slot[j]) * d + c;
     const float va = j < t ? p.va_c[o] : lin[2 * d + c];
@@ -225,6 +227,7 @@ __global__ __launch_bounds__(128) void dynexp_accum_kernel(DynParams p) {
     oa = fmaf(wba[t * EE + e], af, oa);
     ob = fmaf(wbb[t * EE + e], bf, ob);
   }
+#pragma unroll 2
   for (int j = 0; j < t; ++j) {
     const long base = (((long)j * NT + slot[j]) * EE) * d + c;
     float av[EE], bv[EE];
@@ -383,18 +386,43 @@ __global__ __launch_bounds__(1024) void logsoftmax_topk_kernel(const float* __re
   float tv[KM]; int ti[KM];
 #pragma unroll
   for (int q = 0; q < KM; ++q) { tv[q] = -INFINITY; ti[q] = 0x7fffffff; }
-  for (int i = tid; i < V; i += 1024) {
-    float v = x[i]; int vi = i;
-    if (v > tv[KM - 1]) {
+  // V <= 10240 (the 10000-word vocabulary): the row slice of a thread is 10 values — load them all at
+  // once and keep them in registers for both passes; longer rows stream twice.
+  constexpr int NPT = 10;
+  const bool small = V <= NPT * 1024;
+  float xv[NPT];
+  if (small) {
 #pragma unroll
-      for (int q = 0; q < KM; ++q) {
-        if (v > tv[q]) { const float fv = tv[q]; const int fi = ti[q]; tv[q] = v; ti[q] = vi; v = fv; vi = fi; }
+    for (int u = 0; u < NPT; ++u) { const int i = tid + u * 1024; xv[u] = i < V ? x[i] : -INFINITY; }
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+      float v = xv[u]; int vi = tid + u * 1024;
+      if (v > tv[KM - 1]) {
+#pragma unroll
+        for (int q = 0; q < KM; ++q) {
+          if (v > tv[q]) { const float fv = tv[q]; const int fi = ti[q]; tv[q] = v; ti[q] = vi; v = fv; vi = fi; }
+        }
+      }
+    }
+  } else {
+    for (int i = tid; i < V; i += 1024) {
+      float v = x[i]; int vi = i;
+      if (v > tv[KM - 1]) {
+#pragma unroll
+        for (int q = 0; q < KM; ++q) {
+          if (v > tv[q]) { const float fv = tv[q]; const int fi = ti[q]; tv[q] = v; ti[q] = vi; v = fv; vi = fi; }
+        }
       }
     }
   }
   const float m = block_max(tv[0], red);
   float s = 0.f;
-  for (int i = tid; i < V; i += 1024) s += expf(x[i] - m);
+  if (small) {
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) s += expf(xv[u] - m);        // exp(-inf) = 0 for the padding slots
+  } else {
+    for (int i = tid; i < V; i += 1024) s += expf(x[i] - m);
+  }
   s = block_sum(s, red);
   const float lse = m + logf(s);
   if (logp_out)
@@ -451,20 +479,42 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamParams p) {
   const int t = *p.pos;                 // position just processed; prefix length is t+1
   int alive_any = 0;
 
+  // everything lane 0's serial selection touches is first brought into LDS by all 64 lanes
+  // (k² candidates, per-beam flags, the k x (t+1) per-token log-probs): one round of loads in flight
+  // instead of ~k·(t+k) dependent ones
+  __shared__ float s_cv[MAX_K * MAX_K];
+  __shared__ int s_ci[MAX_K * MAX_K];
+  __shared__ int s_eos[MAX_K];
+  __shared__ int s_ne[MAX_K];
+  __shared__ float s_cu[MAX_K];
+  __shared__ float s_lpm[MAX_K][MAX_T];
+  for (int i = lane; i < k * k; i += 64) {
+    s_cv[i] = p.cand_val[(long)b * k * k + i];
+    s_ci[i] = p.cand_idx[(long)b * k * k + i];
+  }
+  for (int r = lane; r < k; r += 64) {
+    s_eos[r] = p.has_eos[b * k + r]; s_ne[r] = p.n_elem[b * k + r]; s_cu[r] = p.cumul[b * k + r];
+  }
+  for (int i = lane; i < k * (t + 1); i += 64) {
+    const int r = i / (t + 1), j = i - r * (t + 1);
+    s_lpm[r][j] = p.lp[((long)b * k + r) * T + j];
+  }
+  __syncthreads();
+
   if (lane == 0) {
     if (t == 0) {                       // seeding: the k best words of beam 0
       for (int r = 0; r < k; ++r) {
         s_parent[r] = 0;
-        s_word[r] = p.cand_idx[((long)b * k) * k + r];
-        s_lp[r] = p.cand_val[((long)b * k) * k + r];
+        s_word[r] = s_ci[r];
+        s_lp[r] = s_cv[r];
       }
     } else {
       float tot[MAX_K * MAX_K];
       for (int j = 0; j < k; ++j) {
-        const int dn = p.has_eos[b * k + j];
-        const float cu = p.cumul[b * k + j];
+        const int dn = s_eos[j];
+        const float cu = s_cu[j];
         for (int c = 0; c < k; ++c) {
-          const float v = dn ? (c == 0 ? 0.0f : -999.0f) : p.cand_val[((long)b * k + j) * k + c];
+          const float v = dn ? (c == 0 ? 0.0f : -999.0f) : s_cv[j * k + c];
           tot[j * k + c] = cu + v;
         }
       }
@@ -474,17 +524,17 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamParams p) {
           if (tot[i] > bvv) { bvv = tot[i]; bi = i; }
         tot[bi] = -INFINITY;
         const int j = bi / k, c = bi - j * k;
-        const int dn = p.has_eos[b * k + j];
+        const int dn = s_eos[j];
         s_parent[r] = j;
-        s_word[r] = p.cand_idx[((long)b * k + j) * k + c];
-        s_lp[r] = dn ? (c == 0 ? 0.0f : -999.0f) : p.cand_val[((long)b * k + j) * k + c];
+        s_word[r] = s_ci[j * k + c];
+        s_lp[r] = dn ? (c == 0 ? 0.0f : -999.0f) : s_cv[j * k + c];
       }
     }
     // cumulative score = re-summed per-token log-probs of the parent prefix + the new one (:213)
     for (int r = 0; r < k; ++r) {
-      const long src = ((long)b * k + s_parent[r]) * T;
+      const float* src = s_lpm[s_parent[r]];
       float cs = 0.f;
-      for (int j = 0; j <= t; ++j) cs += p.lp[src + j];
+      for (int j = 0; j <= t; ++j) cs += src[j];
       s_cumul[r] = cs + s_lp[r];
     }
   }
@@ -512,8 +562,8 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamParams p) {
     int pe[MAX_K], ne[MAX_K];
     for (int r = 0; r < k; ++r) {
       const int par = s_parent[r];
-      pe[r] = t == 0 ? 0 : p.has_eos[b * k + par];
-      ne[r] = t == 0 ? 1 : p.n_elem[b * k + par];
+      pe[r] = t == 0 ? 0 : s_eos[par];
+      ne[r] = t == 0 ? 1 : s_ne[par];
     }
     for (int r = 0; r < k; ++r) {
       const long dst = base + (long)r * T;
