@@ -50,6 +50,8 @@ _SIGNATURES = {
     "odic_cast_f32_to_bf16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P]),
     "odic_patch_merge_layernorm": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _F, _I32, _P]),
     "odic_patch_embed": (C.c_int, [_P] * 6 + [_I32] * 6 + [_F, _P]),
+    "odic_resize_bilinear_normalize": (C.c_int, [_P, _I32, _I32, _I64, _P, _P, _I32, _P, _P, _I32, _P, _P, _I32,
+                                                 C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "odic_window_attention": (C.c_int, [_P, _P, _P, _P] + [_I32] * 6 + [_F, _I32, _P]),
     "odic_stcexp_normalize": (C.c_int, [_P, _P, _P, _I32, _P, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _I32, _P]),
     "odic_selector_mix": (C.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _P]),
