@@ -227,6 +227,15 @@ int odic_logsoftmax_topk(const float* logits, int64_t ldl, float* logp_out, int6
                          float* top_val, int32_t* top_idx, int32_t N, int32_t V, int32_t k,
                          void* stream);
 
+/* Ensemble step distribution (ensemble_captioning_model.py:66-83): `logits` is a HOST array of M (<= 8)
+ * device pointers to fp32 [N, V] logits (row pitch ldl); out[n][v] = log(mean_m softmax(logits_m[n])[v]). */
+int odic_ensemble_logprobs(const float* const* logits, int32_t M, int64_t ldl, float* out, int64_t ldo,
+                           int32_t N, int32_t V, void* stream);
+/* k largest entries of every row (ties → lower index), values taken as they are (rows already hold
+ * log-probabilities, e.g. the output of odic_ensemble_logprobs): top_val fp32 [N,k], top_idx int32 [N,k]. */
+int odic_topk_rows(const float* logp, int64_t ldl, float* top_val, int32_t* top_idx, int32_t N, int32_t V,
+                   int32_t k, void* stream);
+
 /* Beam bookkeeping of one search step on device (captioning_model.py:172-223; the call with
  * *pos == 0 is the seeding of :126-140).  All arrays are device resident.
  *   cand_val/cand_idx [n_img*beams, beams]: per-sequence top-k log-probs / words

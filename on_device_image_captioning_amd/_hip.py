@@ -59,6 +59,8 @@ _SIGNATURES = {
     "odic_dynexp_step": (C.c_int, [_P, _I64, _P, _P] + [_P] * 7 + [_P, _P, _P, _P, _I64, _P, _I64, _P] + [_I32] * 4 + [_F, _P]),
     "odic_cross_attn_step": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P, _P, _P, _I64] + [_I32] * 5 + [_P]),
     "odic_logsoftmax_topk": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _P]),
+    "odic_ensemble_logprobs": (C.c_int, [C.POINTER(C.c_void_p), _I32, _I64, _P, _I64, _I32, _I32, _P]),
+    "odic_topk_rows": (C.c_int, [_P, _I64, _P, _P, _I32, _I32, _I32, _P]),
     "odic_beam_step": (C.c_int, [_P, _P, C.POINTER(BeamState), _I32, _I32, _I32, _I64, _P]),
     "odic_beam_finalize": (C.c_int, [C.POINTER(BeamState), _P, _P, _I32, _I32, _P]),
 }

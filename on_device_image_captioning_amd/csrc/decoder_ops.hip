@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __res
 // Σ exp(x - max).  Then k rounds of block arg-max over the thread heads; the winner pops its
 // head.  Ties → lower index (within a thread indices ascend, across threads compared explicitly).
 // ---------------------------------------------------------------------------------------------
-template <int KM>
+template <int KM, bool NORM = true>
 __global__ __launch_bounds__(1024) void logsoftmax_topk_kernel(const float* __restrict__ logits, long ldl,
                                                                float* __restrict__ logp_out, long ldp,
                                                                float* __restrict__ top_val, int* __restrict__ top_idx,
@@ -415,16 +415,19 @@ __global__ __launch_bounds__(1024) void logsoftmax_topk_kernel(const float* __re
       }
     }
   }
-  const float m = block_max(tv[0], red);
-  float s = 0.f;
-  if (small) {
+  float lse = 0.f;                                               // NORM = false: rows are log-probs already
+  if constexpr (NORM) {
+    const float m = block_max(tv[0], red);
+    float s = 0.f;
+    if (small) {
 #pragma unroll
-    for (int u = 0; u < NPT; ++u) s += expf(xv[u] - m);        // exp(-inf) = 0 for the padding slots
-  } else {
-    for (int i = tid; i < V; i += 1024) s += expf(x[i] - m);
+      for (int u = 0; u < NPT; ++u) s += expf(xv[u] - m);      // exp(-inf) = 0 for the padding slots
+    } else {
+      for (int i = tid; i < V; i += 1024) s += expf(x[i] - m);
+    }
+    s = block_sum(s, red);
+    lse = m + logf(s);
   }
-  s = block_sum(s, red);
-  const float lse = m + logf(s);
   if (logp_out)
     for (int i = tid; i < V; i += 1024) logp_out[(long)n * ldp + i] = x[i] - lse;
   for (int r = 0; r < k; ++r) {
@@ -666,6 +669,57 @@ extern "C" int odic_cross_attn_step(const float* q, int64_t ldq, const float* kv
   else if (beams == 5 || beams > 8) ODIC_XATTN(5);
   else ODIC_XATTN(4);
 #undef ODIC_XATTN
+  return odic_launch_status();
+}
+
+// Ensemble step distribution (ensemble_captioning_model.py:66-83): out[n][v] = log(mean_m softmax(logits_m[n])[v]).
+// One block per row; per model the row max and Σexp, then one pass that averages the probabilities.
+constexpr int MAX_MODELS = 8;
+struct EnsembleParams { const float* logits[MAX_MODELS]; int M; long ldl; float* out; long ldo; int V; };
+
+__global__ __launch_bounds__(1024) void ensemble_logprob_kernel(EnsembleParams p) {
+  __shared__ float red[16];
+  __shared__ float s_max[MAX_MODELS], s_inv[MAX_MODELS];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int m = 0; m < p.M; ++m) {
+    const float* x = p.logits[m] + (long)n * p.ldl;
+    float mx = -INFINITY;
+    for (int i = tid; i < p.V; i += 1024) mx = fmaxf(mx, x[i]);
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int i = tid; i < p.V; i += 1024) s += expf(x[i] - mx);
+    s = block_sum(s, red);
+    if (tid == 0) { s_max[m] = mx; s_inv[m] = 1.0f / s; }
+    __syncthreads();
+  }
+  const float inv_m = 1.0f / (float)p.M;
+  for (int i = tid; i < p.V; i += 1024) {
+    float acc = 0.f;
+    for (int m = 0; m < p.M; ++m) acc += expf(p.logits[m][(long)n * p.ldl + i] - s_max[m]) * s_inv[m];
+    p.out[(long)n * p.ldo + i] = logf(acc * inv_m);
+  }
+}
+
+extern "C" int odic_ensemble_logprobs(const float* const* logits, int32_t M, int64_t ldl, float* out, int64_t ldo,
+                                      int32_t N, int32_t V, void* stream) {
+  if (!logits || !out) return ODIC_ENULL;
+  if (M <= 0 || M > MAX_MODELS || N <= 0 || V <= 0) return ODIC_EINVAL;
+  EnsembleParams p;
+  for (int m = 0; m < MAX_MODELS; ++m) p.logits[m] = m < M ? logits[m] : nullptr;
+  for (int m = 0; m < M; ++m) if (!p.logits[m]) return ODIC_ENULL;
+  p.M = M; p.ldl = ldl; p.out = out; p.ldo = ldo; p.V = V;
+  hipLaunchKernelGGL(ensemble_logprob_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, p);
+  return odic_launch_status();
+}
+
+extern "C" int odic_topk_rows(const float* logp, int64_t ldl, float* top_val, int32_t* top_idx, int32_t N, int32_t V,
+                              int32_t k, void* stream) {
+  if (!logp || !top_val || !top_idx) return ODIC_ENULL;
+  if (N <= 0 || V <= 0 || k <= 0 || k > MAX_K || k > V) return ODIC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (k <= 4) hipLaunchKernelGGL((logsoftmax_topk_kernel<4, false>), dim3(N), dim3(1024), 0, s, logp, (long)ldl, (float*)nullptr, 0L, top_val, top_idx, V, k);
+  else if (k <= 8) hipLaunchKernelGGL((logsoftmax_topk_kernel<8, false>), dim3(N), dim3(1024), 0, s, logp, (long)ldl, (float*)nullptr, 0L, top_val, top_idx, V, k);
+  else hipLaunchKernelGGL((logsoftmax_topk_kernel<16, false>), dim3(N), dim3(1024), 0, s, logp, (long)ldl, (float*)nullptr, 0L, top_val, top_idx, V, k);
   return odic_launch_status();
 }
 

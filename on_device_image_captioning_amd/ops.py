@@ -349,6 +349,25 @@ def logsoftmax_topk(logits, ldl, logp_out, ldp, top_val, top_idx, N, V, k) -> No
                                                     k, _stream()), "odic_logsoftmax_topk")
 
 
+def ensemble_logprobs(logits_list, out: torch.Tensor) -> None:
+    """out[n] = log(mean_m softmax(logits_m[n])) — ensemble_captioning_model.py:66-83."""
+    _need_cuda(out, *logits_list)
+    M = len(logits_list)
+    N, V = out.shape
+    arr = (C.c_void_p * M)(*[t.data_ptr() for t in logits_list])
+    with _timed("ensemble_logprobs", 0.0, 4.0 * (M + 1) * N * V):
+        _hip.check(_hip.load().odic_ensemble_logprobs(arr, M, logits_list[0].stride(0), _p(out), out.stride(0), N, V,
+                                                      _stream()), "odic_ensemble_logprobs")
+
+
+def topk_rows(logp: torch.Tensor, top_val: torch.Tensor, top_idx: torch.Tensor, k: int) -> None:
+    _need_cuda(logp, top_val, top_idx)
+    N, V = logp.shape
+    with _timed("logsoftmax_topk", 0.0, 4.0 * N * V):
+        _hip.check(_hip.load().odic_topk_rows(_p(logp), logp.stride(0), _p(top_val), _p(top_idx), N, V, k, _stream()),
+                   "odic_topk_rows")
+
+
 def beam_step(cand_val, cand_idx, state: "_hip.BeamState", n_img, beams, T, eos_idx) -> None:
     with _timed("beam_step", 0.0, 0.0):
         _hip.check(_hip.load().odic_beam_step(_p(cand_val), _p(cand_idx), C.byref(state), n_img, beams, T, eos_idx,

@@ -280,11 +280,15 @@ def forward_teacher(sd: SD, g, enc_x, dec_x, enc_num_pads, dec_num_pads, log_sof
     return decoder_forward(sd, g, mem, enc_num_pads, dec_x, dec_num_pads, log_softmax, end_to_end)
 
 
-def beam_search(sd: SD, g, enc_x: torch.Tensor, enc_num_pads: Sequence[int], sos_idx: int,
+def beam_search(sd, g, enc_x: torch.Tensor, enc_num_pads: Sequence[int], sos_idx: int,
                 eos_idx: int, beam_size: int = 3, how_many_outputs: int = 1, max_seq_len: int = 20,
                 end_to_end: bool = True, trace: list | None = None
                 ) -> Tuple[List[List[List[int]]], torch.Tensor]:
     """captioning_model.py:111-241 ('max' branch), with plain tensors.
+
+    `sd` may also be a LIST of state dicts: the ensemble search of ensemble_captioning_model.py:48-83 —
+    every model encodes and decodes on its own, the per-step distribution is log(mean_m softmax(logits_m))
+    and the search itself (:87-291, a copy of the single-model loop) is unchanged.
 
     State per image b and beam j:  toks[b,j,:t], lps[b,j,:t] (per-token log-probs, slot 0 = 0),
     n_elem[b,j] (length incl. SOS and EOS).  `trace`, if given, receives per-step
@@ -292,23 +296,29 @@ def beam_search(sd: SD, g, enc_x: torch.Tensor, enc_num_pads: Sequence[int], sos
     assert how_many_outputs <= beam_size
     B, k = enc_x.shape[0], beam_size
     enc_num_pads = list(enc_num_pads)
-    mem = forward_enc(sd, g, enc_x, enc_num_pads, end_to_end)
+    sds = list(sd) if isinstance(sd, (list, tuple)) else [sd]
+    mems = [forward_enc(s_, g, enc_x, enc_num_pads, end_to_end) for s_ in sds]
+
+    def logprobs(mem_list, pads, toks_, dec_pads):
+        if len(sds) == 1:
+            return decoder_forward(sds[0], g, mem_list[0], pads, toks_, dec_pads, True, end_to_end)
+        probs = [torch.softmax(decoder_forward(s_, g, m_, pads, toks_, dec_pads, False, end_to_end), dim=-1)
+                 for s_, m_ in zip(sds, mem_list)]
+        return torch.stack(probs, 0).mean(0).log()                          # ensemble_captioning_model.py:66-83
 
     # ---- first step: one distribution per image, its top-k seed the beams (:117-140)
-    lp0 = decoder_forward(sd, g, mem, enc_num_pads, torch.full((B, 1), sos_idx, dtype=torch.long),
-                          [0] * B, True, end_to_end)[:, 0]
+    lp0 = logprobs(mems, enc_num_pads, torch.full((B, 1), sos_idx, dtype=torch.long), [0] * B)[:, 0]
     v0, w0 = torch.topk(lp0, k, dim=-1)
     toks = torch.stack([torch.full((B, k), sos_idx, dtype=torch.long), w0], -1)      # (B,k,2)
     lps = torch.stack([torch.zeros(B, k), v0], -1)
     cumul = lps.sum(-1)
     n_elem = torch.full((B, k), 2, dtype=torch.long)
-    mem_k = mem[:, None].expand(B, k, *mem.shape[1:]).reshape(B * k, *mem.shape[1:])
+    mems_k = [m_[:, None].expand(B, k, *m_.shape[1:]).reshape(B * k, *m_.shape[1:]) for m_ in mems]
     pads_k = [p for p in enc_num_pads for _ in range(k)]
     bidx = torch.arange(B)[:, None]
 
     for t in range(2, max_seq_len):
-        lp = decoder_forward(sd, g, mem_k, pads_k, toks.reshape(B * k, t),
-                             (t - n_elem).reshape(-1).tolist(), True, end_to_end)[:, t - 1]
+        lp = logprobs(mems_k, pads_k, toks.reshape(B * k, t), (t - n_elem).reshape(-1).tolist())[:, t - 1]
         cv, cw = torch.topk(lp, k, dim=-1)                                  # (B*k, k)
         cv, cw = cv.view(B, k, k).clone(), cw.view(B, k, k)
         done = (toks == eos_idx).any(-1)                                    # (B,k)

@@ -199,3 +199,19 @@ def test_cider_d_matches_reference_scorer():
         assert abs(score - c["score"]) < 1e-9
         np.testing.assert_allclose(scores, c["scores"], atol=1e-9)
     assert max(c["score"] for c in cases) > 1.0       # non-degenerate fixtures
+
+
+# ----------------------------------------------------------------------------------- F4 ensemble
+@pytest.mark.parametrize("name", ["two", "three"])
+@pytest.mark.parametrize("beam", [3, 1])
+def test_oracle_ensemble_search_matches_reference(name, beam):
+    """oracle beam_search over a LIST of checkpoints = the reference's EsembleCaptioningModel
+    (fixtures: oracle/make_golden_ensemble.py)."""
+    store = np.load(os.path.join(GOLDEN, "tiny_ensemble.npz"))
+    g = W.TINY
+    sds = [W.synth_state_dict(g, seed=int(s), variant=str(v), eos_idx=2)
+           for s, v in zip(store[name + ".seeds"], store[name + ".variants"])]
+    img = W.synth_images(3, g)
+    pred, lp = R.beam_search(sds, g, img, [0] * 3, 3, 2, beam, beam, 12)
+    assert pred == unpad(store[f"{name}.beam{beam}_T12.tokens"])
+    np.testing.assert_allclose(lp.numpy(), store[f"{name}.beam{beam}_T12.logprobs"], atol=2e-5)
