@@ -441,3 +441,37 @@ def test_ensemble_beam_search_matches_reference(name, beam):
     np.testing.assert_allclose(lp.cpu().numpy(), store[f"{name}.beam{beam}_T12.logprobs"], atol=1e-3)
     with pytest.raises(AssertionError):
         ens(enc_x=img, enc_x_num_pads=[0] * 3, mode="forward")
+
+
+# ----------------------------------------------------------------------------------------- config 4 shape
+@pytest.mark.parametrize("variant", ["xavier", "eos"])
+def test_long_beam5_search_matches_reference_tiny(variant):
+    """beam 5 / beam 3 at beam_max_seq_len = max_seq_len (every position of the pos-encoder table is used)."""
+    store = np.load(os.path.join(GOLDEN, "tiny_long.npz"))
+    g = W.TINY
+    m = build_model("TINY", variant)
+    img = W.synth_images(3, g).to(DEV)
+    for k in (5, 3):
+        pred, lp = m(enc_x=img, enc_x_num_pads=[0] * 3, mode="beam_search", beam_size=k, how_many_outputs=2,
+                     beam_max_seq_len=g.max_seq_len, sample_or_max="max", sos_idx=TSOS, eos_idx=TEOS)
+        assert pred == unpad(store[f"{variant}.beam{k}_T{g.max_seq_len}.tokens"])
+        np.testing.assert_allclose(lp.cpu().numpy(), store[f"{variant}.beam{k}_T{g.max_seq_len}.logprobs"], atol=1e-3)
+
+
+@pytest.mark.parametrize("variant", ["xavier", "eos"])
+def test_full_geometry_beam5_T74_matches_reference(variant):
+    """BASELINE config 4 per-image shape: Swin-L/384, beam 5, beam_max_seq_len 74 (demo.py:21), fp32 mode —
+    direct call and the hipGraph pipeline (early stop through the device `done` flag on the eos checkpoint)."""
+    from on_device_image_captioning_amd.pipeline import CaptionPipeline
+    store = np.load(os.path.join(GOLDEN, "full_long.npz"))
+    g = W.FULL
+    m = build_model("FULL", variant)
+    img = W.synth_images(2, g).to(DEV)
+    pred, lp = m(enc_x=img, enc_x_num_pads=[0] * 2, mode="beam_search", beam_size=5, how_many_outputs=2,
+                 beam_max_seq_len=74, sample_or_max="max", sos_idx=SOS, eos_idx=EOS)
+    want = unpad(store[f"{variant}.beam5_T74.tokens"])
+    assert pred == want
+    np.testing.assert_allclose(lp.cpu().numpy(), store[f"{variant}.beam5_T74.logprobs"], atol=2e-3)
+    pipe = CaptionPipeline(m, 2, 5, 74, SOS, EOS, done_poll=4)
+    assert pipe(img) == [per[0] for per in want]
+    assert pipe(img.flip(0).contiguous()) == [per[0] for per in want][::-1]

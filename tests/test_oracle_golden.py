@@ -215,3 +215,15 @@ def test_oracle_ensemble_search_matches_reference(name, beam):
     pred, lp = R.beam_search(sds, g, img, [0] * 3, 3, 2, beam, beam, 12)
     assert pred == unpad(store[f"{name}.beam{beam}_T12.tokens"])
     np.testing.assert_allclose(lp.numpy(), store[f"{name}.beam{beam}_T12.logprobs"], atol=2e-5)
+
+
+# ----------------------------------------------------------------------------------- config-4 shape
+@pytest.mark.parametrize("variant", ["xavier", "eos"])
+def test_oracle_long_beam5_search_matches_reference(variant):
+    """beam 5 at beam_max_seq_len = max_seq_len (the demo.py / COCO-evaluation shape) on the TINY geometry."""
+    store = np.load(os.path.join(GOLDEN, "tiny_long.npz"))
+    g = W.TINY
+    sd = W.synth_state_dict(g, variant=variant, eos_idx=2)
+    pred, lp = R.beam_search(sd, g, W.synth_images(3, g), [0] * 3, 3, 2, 5, 2, g.max_seq_len)
+    assert pred == unpad(store[f"{variant}.beam5_T{g.max_seq_len}.tokens"])
+    np.testing.assert_allclose(lp.numpy(), store[f"{variant}.beam5_T{g.max_seq_len}.logprobs"], atol=2e-5)
