@@ -152,13 +152,13 @@ def cpu_baseline(sd, g, runs, beam, max_len):
     from oracle import expansionnet_ref as R
     img = W.synth_images(1, g)
 
-    def timed(n):
+    def timed(n, k=beam):
         with torch.no_grad():
-            R.beam_search(sd, g, img, [0], SOS, EOS, beam, 1, max_len)        # warm-up
+            R.beam_search(sd, g, img, [0], SOS, EOS, k, 1, max_len)           # warm-up
             ts = []
             for _ in range(n):
                 t0 = time.perf_counter()
-                R.beam_search(sd, g, img, [0], SOS, EOS, beam, 1, max_len)
+                R.beam_search(sd, g, img, [0], SOS, EOS, k, 1, max_len)
                 ts.append(time.perf_counter() - t0)
         ts.sort()
         return ts[len(ts) // 2], sum(ts) / len(ts)
@@ -172,8 +172,13 @@ def cpu_baseline(sd, g, runs, beam, max_len):
     best = min(results, key=lambda k: results[k][0])
     med, mean = results[best]
     detail = "; ".join(f"{k} threads: median {v[0]:.3f}s mean {v[1]:.3f}s per caption" for k, v in results.items())
+    torch.set_num_threads(best)
+    gmed, _ = timed(max(2, runs // 2), 1)                   # greedy = BASELINE configs[0] (demo.py CPU path)
+    torch.set_num_threads(default_threads)
     return {"value": round(1.0 / med, 4), "unit": "captions/s", "cores": best, "kind": "port",
+            "greedy_value": round(1.0 / gmed, 4),
             "sample": f"B=1 (demo.py shape), beam {beam}, T={max_len}, fp32 oracle, median per caption; {detail}; "
+                      f"greedy (beam 1) with {best} threads: median {gmed:.3f}s per caption; "
                       f"os.cpu_count()={os.cpu_count()}"}
 
 
