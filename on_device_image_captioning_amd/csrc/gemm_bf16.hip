@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
 //     1    (A0, W0)   W0: 4, A0: 8 ds_read_b128    A1 of K-tile c+1
 //     2    (A0, W1)   W1: 4 (A0 stays in regs)     W0 of K-tile c+1
 //     3    (A1, W1)   A1: 8 (W1 stays)             A0 of K-tile c+2   (A0 of c: last read in phase 1)
-//     4    (A1, W0)   W0: 4 (A1 stays)             W1 of K-tile c+2   (W1 of c: last read in phase 2)
+//     4    (A1, W0)   none (W0 kept from phase 1)  W1 of K-tile c+2   (W1 of c: last read in phase 2)
 //
 // so every half-tile buffer is restaged two phases after its last read (WAR) and is read no earlier
 // than the phase after the counted wait + barrier that retires it (RAW): the
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256sq_kernel(Params p) {
   const int a_off = (wr * 64 + frow) * 128, w_off = (wc * 32 + frow) * 128;
   const int c0 = ((0 + fq) ^ (frow & 7)) << 4, c1 = ((4 + fq) ^ (frow & 7)) << 4;   // kk = 0 / 1 chunks
 
-  bf16x8_t af[4][2], wf[2][2];                                     // [mi or ni][kk]
+  bf16x8_t af[4][2], wf[2][2][2];                                  // [mi][kk], [W half][ni][kk]: both W halves stay live
   auto read_a = [&](int parity, int h) {
     const char* b = lds + (parity * 4 + h) * HALF + a_off;
 #pragma unroll
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256sq_kernel(Params p) {
     const char* b = lds + (parity * 4 + 2 + h) * HALF + w_off;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-      wf[ni][0] = *(const bf16x8_t*)(b + ni * 16 * 128 + c0);
-      wf[ni][1] = *(const bf16x8_t*)(b + ni * 16 * 128 + c1);
+      wf[h][ni][0] = *(const bf16x8_t*)(b + ni * 16 * 128 + c0);
+      wf[h][ni][1] = *(const bf16x8_t*)(b + ni * 16 * 128 + c1);
     }
   };
   auto mma = [&](int i, int j) {
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256sq_kernel(Params p) {
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
-          acc[i][j][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][kk], af[mi][kk], acc[i][j][mi][ni], 0, 0, 0);
+          acc[i][j][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ni][kk], af[mi][kk], acc[i][j][mi][ni], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -367,8 +367,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256sq_kernel(Params p) {
     __builtin_amdgcn_s_barrier();
     mma(1, 1);
     __builtin_amdgcn_s_barrier();
-    // ---- phase 4: quadrant (A1, W0); the counted wait retires every half-tile of K-tile c+1
-    read_w(parity, 0);
+    // ---- phase 4: quadrant (A1, W0) — W0 fragments are still in registers from phase 1; the counted wait
+    //      retires every half-tile of K-tile c+1
     if (c + 2 < nk) {
       stage(parity, 3, c + 2);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
