@@ -269,22 +269,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256sq_kernel(Params p) {
   const bf16_raw* A = p.A + bz * p.strideA;
   const bf16_raw* W = p.W + bz * p.strideW;
 
-  // ---- LDS-DMA sources: a half-tile is 16 pieces of 1 KiB (8 rows x 128 B); wave w moves pieces 2w, 2w+1
+  // ---- LDS-DMA sources: a half-tile is 16 pieces of 1 KiB (8 rows x 128 B); wave w moves pieces 2w, 2w+1.
+  //      buffer_load ... lds with the tile's base in a scalar resource descriptor, a 32-bit per-lane byte
+  //      offset and the K-tile advance as the scalar offset: no per-issue 64-bit address arithmetic, and the
+  //      LDS-DMA issues cheaper than the flat-address form (it is the long pole of a phase's load segment).
   const int srow = lane >> 3, schunk = (lane & 7) ^ srow;          // swizzle: chunk ^ (row & 7)
-  const bf16_raw* src[4][2];                                       // [A0, A1, W0, W1][piece]
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(A + (long)m0 * p.lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(W + (long)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  int voff[4][2];                                                  // [A0, A1, W0, W1][piece] byte offsets
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = (wave * 2 + i) * 8 + srow;                     // row inside the half-tile
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      src[h][i] = A + (long)min(m0 + h * 128 + row, p.M - 1) * p.lda + schunk * 8;
-      src[2 + h][i] = W + (long)min(n0 + h * 128 + wperm(row), p.N - 1) * p.ldw + schunk * 8;
+      voff[h][i] = (min(m0 + h * 128 + row, p.M - 1) - m0) * (int)p.lda * 2 + schunk * 16;
+      voff[2 + h][i] = (min(n0 + h * 128 + wperm(row), p.N - 1) - n0) * (int)p.ldw * 2 + schunk * 16;
     }
   }
   auto stage = [&](int parity, int h, int kt) {
     char* dst = lds + (parity * 4 + h) * HALF + wave * 2048;
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[h][0] + (long)kt * 64), (lptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[h][1] + (long)kt * 64), (lptr_t)(dst + 1024), 16, 0, 0);
+    const __amdgpu_buffer_rsrc_t r = h < 2 ? rsrc_a : rsrc_w;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)dst, 16, voff[h][0], kt * 128, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)(dst + 1024), 16, voff[h][1], kt * 128, 0, 0);
   };
 
   f32x4_t acc[2][2][4][2];                                         // [A half][W half][mi][ni]
@@ -485,6 +493,8 @@ int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
 int launch_256sq(Params& p, int out_dtype, int batch, hipStream_t stream) {
   constexpr int SHMEM = 128 * 1024;
   if (p.K % 128 != 0) return ODIC_EINVAL;
+  if (256L * p.lda * 2 + 2L * p.K >= 0x7fffffffL || 256L * p.ldw * 2 + 2L * p.K >= 0x7fffffffL)
+    return ODIC_EINVAL;                        // 32-bit byte offsets inside a tile's buffer resource
   p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
   int pn = 1;
   while (pn < 8 && pn * 2 <= p.tiles_n && (double)p.N / pn * p.K * 2.0 > 2.5 * 1024 * 1024) pn *= 2;
