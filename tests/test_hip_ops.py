@@ -269,6 +269,25 @@ def test_logsoftmax_topk(ops):
     assert_close(tv, wv, 2e-6, "topk values")
 
 
+def test_ensemble_logprobs_and_topk_rows(ops):
+    # log(mean_m softmax(logits_m)) and its row-wise top-k (ties → lower index), the two ensemble-step kernels
+    N, V, M, k = 7, 10000, 3, 5
+    logits = [rnd(N, V, seed=10 + m, scale=3.0) for m in range(M)]
+    want = torch.stack([torch.softmax(l.double(), -1) for l in logits]).mean(0).log()
+    out = torch.empty(N, V, device="cuda")
+    ops.ensemble_logprobs([dev(l) for l in logits], out)
+    assert_close(out, want, 2e-6, "ensemble_logprobs")
+    out[2, 17] = out[2, 4000] = out[2].max() + 1.0          # an exact tie: the lower index must win
+    tv = torch.empty(N, k, device="cuda")
+    ti = torch.empty(N, k, dtype=torch.int32, device="cuda")
+    ops.topk_rows(out, tv, ti, k)
+    ref_v, ref_i = torch.topk(out.cpu(), k, dim=-1)
+    assert torch.equal(tv.cpu(), ref_v)
+    assert ti[2, 0].item() == 17 and ti[2, 1].item() == 4000
+    rows = [r for r in range(N) if r != 2]
+    assert torch.equal(ti.cpu()[rows].long(), ref_i[rows])
+
+
 @pytest.mark.parametrize("beams,S,d,heads", [(2, 20, 128, 4), (1, 144, 512, 8), (3, 144, 512, 8), (5, 144, 512, 8),
                                              (7, 50, 128, 8), (11, 33, 64, 4)])
 def test_cross_attn_step(ops, beams, S, d, heads):
