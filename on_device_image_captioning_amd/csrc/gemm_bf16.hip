@@ -74,6 +74,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / NWN, wn = wave % NWN;
+  ODIC_ENCODE_PRIO();
 
   // XCD x = blockIdx % 8 owns tile rows [r0,r1) x cols [c0,c1); inside the rectangle tiles run N-fastest
   int tm, tn;
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256sq_kernel(Params p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  ODIC_ENCODE_PRIO();
 
   int tm, tn;
   {

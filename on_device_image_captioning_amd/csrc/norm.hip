@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  if (M >= 1024) ODIC_ENCODE_PRIO();          // backbone-sized launches only (the decoder's 48-row norms stay at 0)
   const int C4 = C >> 2;
 
   // source pointer of float4 index v of this row

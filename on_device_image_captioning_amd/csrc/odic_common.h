@@ -11,6 +11,15 @@ typedef unsigned short bf16_raw;
 
 #define ODIC_WAVE 64
 
+// Kernels of the encode pass (bf16 GEMM, window attention, LayerNorm) raise their wave priority: on a CU they
+// share with a decoder-step block their instructions win the issue arbitration, which shortens the tail every
+// GEMM launch waits for (the step kernels are latency-bound and barely notice).  -DODIC_NO_ENCODE_PRIO disables.
+#ifdef ODIC_NO_ENCODE_PRIO
+#define ODIC_ENCODE_PRIO() ((void)0)
+#else
+#define ODIC_ENCODE_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
 __device__ __forceinline__ float bf16_to_f32(bf16_raw h) {
   return __uint_as_float(((unsigned)h) << 16);
 }

@@ -329,6 +329,7 @@ __global__ __launch_bounds__(192, 5) void window_attention_bf16_v2_kernel(WinPar
   // Block → (window, head): blocks b, b+8, ... share an XCD and its L2.  Each XCD walks its windows with
   // the HEAD index fastest, so the 64-byte q/k/v segments of neighbouring heads — two per 128-byte
   // line — are requested back-to-back from the same L2 and every HBM line is fetched once.
+  ODIC_ENCODE_PRIO();
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int head = idx % p.heads;
   const int win = (idx / p.heads) * 8 + xcd;
