@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void stcexp_fw_kernel(const float* __restrict_
                                                         const int* __restrict__ enc_len,
                                                         OutT* __restrict__ pos_fw, OutT* __restrict__ neg_fw,
                                                         int B, int nq, int S, int ld, float eps) {
+  ODIC_ENCODE_PRIO();
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long)B * nq) return;
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(512) void stcexp_colsum_kernel(const float* __restr
                                                             const int* __restrict__ group_start,
                                                             float* __restrict__ colsum,   // [B, G, 2, S]
                                                             int nq, int S) {
+  ODIC_ENCODE_PRIO();
   __shared__ float rp[8][64];
   __shared__ float rn[8][64];
   const int s = blockIdx.x * 64 + threadIdx.x;
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(256) void stcexp_bw_kernel(const float* __restrict_
                                                         const int* __restrict__ group_of_q,
                                                         OutT* __restrict__ pos_bw, OutT* __restrict__ neg_bw,
                                                         int nq, int S, int ld, int G, float eps, float inv_g) {
+  ODIC_ENCODE_PRIO();
   __shared__ float tp[32][33];
   __shared__ float tn[32][33];
   const int b = blockIdx.z;
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(256) void selector_mix_kernel(const float* __restri
                                                            const float* __restrict__ a, long lda,
                                                            const float* __restrict__ b, long ldb,
                                                            float* __restrict__ out, long ldo, int M, int d) {
+  ODIC_ENCODE_PRIO();
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)M * d) return;
   const int r = i / d, c = i - (long)r * d;

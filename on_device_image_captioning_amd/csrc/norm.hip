@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
                                                           const float* __restrict__ beta, float* __restrict__ out,
                                                           int B, int in_chans, int H, int W, int patch, int C,
                                                           float eps) {
+  ODIC_ENCODE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int K = in_chans * patch * patch;
   constexpr int cpt = CPT;
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, long ldx,
                                                         bf16_raw* __restrict__ out, long ldo, int M, int C4) {
+  ODIC_ENCODE_PRIO();
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)M * C4) return;
   const int r = i / C4, c = (i - (long)r * C4) * 4;
