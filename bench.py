@@ -1,29 +1,40 @@
 #!/usr/bin/env python3
-"""bench.py — captions/sec of the end-to-end ExpansionNet v2 path on N MI355X (one process per GPU).
+"""bench.py — captions/sec of the ExpansionNet v2 hot path on N MI355X (one process per GPU).
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload e2e16|features48|coco5k]
 
-A "step" = one pass of the hot path over one batch on every rank: 16 synthetic 384x384 images →
-Swin-L → expansion encoder → beam-3 search (beam_max_seq_len 20; synthetic xavier weights never emit
-EOS so every caption runs the full 19 decoder steps) → RCCL all_gather of the token ids (N > 1).
-BASELINE.json configs[2]: "End_ExpansionNet_v2 end-to-end with Swin-L 384 backbone, batch 16 bf16,
-beam=3, 1xMI355X".  Inputs are resident in HBM when the timed region starts.  Weak scaling: every
-rank processes its own batch of 16.
+With N > 1 and no torchrun environment the script launches its own N ranks (fresh child processes, one per
+GPU, started before this process makes any GPU call); under `python -m torch.distributed.run` it is one of
+the ranks.  It never falls back to fewer ranks than asked: a mismatch exits non-zero.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      for the dominant kernel family (by time), measured in an extra instrumented pass of
-                the same workload with HIP events on the launch stream (torch.cuda.Event on the
-                current stream = the stream the kernels are launched on)
-  cpu_baseline  the CPU oracle (oracle/expansionnet_ref.py, kind "port") on the host cores, same
-                model, B=1 (the demo.py shape), beam 3, T=20 — a bounded sample, reported not targeted
+Workloads (`config.workload` in the output line):
+  e2e16       BASELINE.json configs[2] (the headline metric): 16 synthetic 384x384 images per GPU per step →
+              Swin-L → expansion encoder → beam-3 search, beam_max_seq_len 20, bf16 backbone/encoder.
+  features48  configs[1]: features-only ExpansionNet_v2, 48 feature sets (144 x 1536) per step, beam 3, fp32.
+  coco5k      configs[3] per-GPU shape: a step = 625 images (5000 / 8 ranks) in sub-batches of 16, beam 5,
+              beam_max_seq_len 74, then ONE RCCL all_gather of the token ids — inside the timed step.
+Synthetic xavier weights never emit EOS, so every caption runs its full decode length.  Inputs are resident
+in HBM when the timed region starts.  Weak scaling: every rank processes its own batch / shard.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+  roofline      dominant kernel family (by time) of the step, HIP events on the launch stream around every
+                C-ABI call in one instrumented eager pass (torch.cuda.Event on the current stream = the stream
+                the kernels are launched on); `kernels` lists every family
+  parity        e2e16: captions of the last timed batch == the un-pipelined direct call (exact), and CIDEr-D of
+                the benchmarked mode's captions against the fp32 mode's captions (= the reference's, token for
+                token) over --cider-images synthetic images
+  fp32_value    e2e16, N = 1: captions/s of the bit-exact fp32 mode, timed in the same run
+  cpu_baseline  N = 1: the CPU oracle (oracle/expansionnet_ref.py, kind "port") on the host cores, B=1 (the
+                demo.py shape) — a bounded sample, reported not targeted
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,47 +42,145 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}     # MI355X_MICROARCH.md
 SOS, EOS = 79, 77
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+
+WORKLOADS = {
+    "e2e16": dict(
+        desc="End_ExpansionNet_v2 end-to-end, Swin-L/384 backbone, batch 16 per GPU, beam 3, beam_max_seq_len 20 "
+             "(BASELINE.json configs[2])",
+        batch=16, beam=3, max_len=20, precision="bf16", steps=40, warmup=4),
+    "features48": dict(
+        desc="ExpansionNet_v2 features-only (N_enc=3, N_dec=3, d=512), batch 48 per GPU, features (48,144,1536), "
+             "beam 3, beam_max_seq_len 20 (BASELINE.json configs[1])",
+        batch=48, beam=3, max_len=20, precision="fp32", steps=40, warmup=4),
+    "coco5k": dict(
+        desc="COCO Karpathy-test 5k shape: 625 images per GPU (5000 over 8 ranks) in sub-batches of 16, beam 5, "
+             "beam_max_seq_len 74, one RCCL all_gather of the token ids inside the step (BASELINE.json configs[3])",
+        batch=16, beam=5, max_len=74, precision="bf16", steps=2, warmup=1, shard=625),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--beam", type=int, default=3)
-    ap.add_argument("--max-len", type=int, default=20)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="e2e16", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--beam", type=int, default=None)
+    ap.add_argument("--max-len", type=int, default=None)
+    ap.add_argument("--shard", type=int, default=None, help="coco5k: images per rank per step")
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp32"])
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-mode timing (e2e16, N = 1)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the direct-call and CIDEr-D checks")
+    ap.add_argument("--cider-images", type=int, default=256)
+    ap.add_argument("--fp32-steps", type=int, default=10)
     ap.add_argument("--cpu-runs", type=int, default=6)
     ap.add_argument("--decode-lanes", type=int, default=2)
     ap.add_argument("--encode-lanes", type=int, default=1,
                     help="encode graphs (one batch each) that may run concurrently on their own HIP streams")
     ap.add_argument("--decode-group", type=int, default=1,
                     help="consecutive batches searched together by one decode lane (rows per step kernel = group*batch*beam)")
-    return ap.parse_args()
+    ap.add_argument("--cpu-selftest", action="store_true",
+                    help="rank plumbing only (gloo, no GPU, no model): used by tests/test_bench_spawn.py")
+    a = ap.parse_args()
+    w = WORKLOADS[a.workload]
+    for k in ("steps", "warmup", "batch", "beam", "precision"):
+        if getattr(a, k) is None:
+            setattr(a, k, w[k])
+    if a.max_len is None:
+        a.max_len = w["max_len"]
+    if a.shard is None:
+        a.shard = w.get("shard", 0)
+    return a
 
 
-def build_model(device, precision):
+# =================================================================================================
+# rank launcher
+# =================================================================================================
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start N fresh ranks of this script (one per GPU) and wait.
+    This parent has not touched the GPU (counting devices does not initialise it); nothing is exec'ed from a
+    process that has.  Returns the exit code to leave with: non-zero if any rank failed."""
+    if "--cpu-selftest" not in sys.argv:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; refusing to run fewer ranks", file=sys.stderr)
+            return 3
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ODIC_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    for q in pending:              # one rank failed: the others would hang in a collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# =================================================================================================
+# model / pipeline
+# =================================================================================================
+def build_model(device, precision, workload):
+    import torch  # noqa: F401
     from on_device_image_captioning_amd import weights as W
     from on_device_image_captioning_amd.End_ExpansionNet_v2 import End_ExpansionNet_v2, make_drop_args
     g = W.FULL
-    sd = W.synth_state_dict(g, variant="xavier")
-    m = End_ExpansionNet_v2(**g.model_kwargs(), output_word2idx={i: i for i in range(g.vocab_size)},
-                            output_idx2word=list(range(g.vocab_size)), drop_args=make_drop_args(), rank=device)
+    vocab = dict(output_word2idx={i: i for i in range(g.vocab_size)}, output_idx2word=list(range(g.vocab_size)))
+    if workload == "features48":
+        from on_device_image_captioning_amd.ExpansionNet_v2 import ExpansionNet_v2
+        sd = W.synth_state_dict(g, variant="xavier", end_to_end=False, img_feature_dim=g.final_swin_dim)
+        m = ExpansionNet_v2(d_model=g.d_model, N_enc=g.N_enc, N_dec=g.N_dec, ff=g.ff, num_heads=g.num_heads,
+                            num_exp_enc_list=list(g.num_exp_enc_list), num_exp_dec=g.num_exp_dec,
+                            max_seq_len=g.max_seq_len, drop_args=make_drop_args(), img_feature_dim=g.final_swin_dim,
+                            rank=device, **vocab)
+    else:
+        sd = W.synth_state_dict(g, variant="xavier")
+        m = End_ExpansionNet_v2(**g.model_kwargs(), drop_args=make_drop_args(), rank=device, **vocab)
     m.load_state_dict(sd, strict=True)
     m.to(device).eval().set_precision(precision)
     return m, sd, g
 
 
+def make_pipe(model, a):
+    from on_device_image_captioning_amd.pipeline import CaptionPipeline
+    return CaptionPipeline(model, a.batch, a.beam, a.max_len, SOS, EOS, use_graphs=not a.no_graphs,
+                           decode_lanes=a.decode_lanes, decode_group=a.decode_group, encode_lanes=a.encode_lanes)
+
+
 def roofline_pass(pipe, images):
-    """One extra eager pass of the same workload with per-launch HIP events."""
+    """One extra eager pass of the same batch with per-launch HIP events."""
+    import torch
     from on_device_image_captioning_amd import ops
     g_encs, g_step = pipe.g_encs, pipe.g_step
     pipe.g_encs, pipe.g_step = [None] * pipe.E, [None] * pipe.D   # eager launches: events bracket single kernels
@@ -98,8 +207,7 @@ def roofline_pass(pipe, images):
             blk["launches"] += 1
     if blk["launches"]:
         fam["swin_attention_block(qkv+core+proj)"] = blk
-    for name, flops, nbytes, s, e, detail in recs:
-        ms = s.elapsed_time(e)
+    for (name, flops, nbytes, s, e, detail), (_, _, _, ms) in zip(recs, times):
         for key, table in ((name, fam), (f"{name}:{detail}", shapes)):
             d = table.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             d["ms"] += ms
@@ -115,50 +223,69 @@ def roofline_pass(pipe, images):
     return fam
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the HIP sources: tells whether the committed PMC traffic file describes this code."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "on_device_image_captioning_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+_PMC = None
+
+
 def pmc_traffic(name):
-    """HBM bytes per launch of a kernel family from the committed PMC passes (profiles/, collected with
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled as the gfx950 guide
-    prescribes).  bench.py cannot read hardware counters itself."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f).get(name, {}).get("hbm_bytes_per_launch")
-    except OSError:
-        return None
+    """HBM bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs of this very command; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
+    prescribes; tools/pmc_traffic_json.py).  bench.py cannot read hardware counters itself."""
+    global _PMC
+    if _PMC is None:
+        try:
+            with open(PMC_FILE) as f:
+                _PMC = json.load(f)
+        except OSError:
+            _PMC = {}
+    return _PMC.get(name, {}).get("hbm_bytes_per_launch")
 
 
 def roofline_entry(name, d):
     sec = d["ms"] * 1e-3
-    if name.startswith("gemm") or name.startswith("swin_attention_block"):
+    mfma = name.startswith("gemm") or name.startswith("swin_attention_block")
+    if mfma:
         peak = PEAK["mfma_f32_tflops"] if name == "gemm_f32" else PEAK["mfma_bf16_tflops"]
         ach = d["flops"] / sec / 1e12
-        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": pmc_traffic(name), "launches": d["launches"],
-                "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
-                "algorithmic_flops_per_step": d["flops"],
-                "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"])}
-    ach = d["bytes"] / sec / 1e9
-    return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK["hbm_gbs"], "unit": "GB/s",
-            "frac": round(ach / PEAK["hbm_gbs"], 4), "traffic": pmc_traffic(name), "launches": d["launches"],
-            "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2), "algorithmic_bytes_per_step": d["bytes"],
-            "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"])}
+        e = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+             "frac": round(ach / peak, 4), "algorithmic_flops_per_step": d["flops"]}
+    else:
+        ach = d["bytes"] / sec / 1e9
+        e = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK["hbm_gbs"], "unit": "GB/s",
+             "frac": round(ach / PEAK["hbm_gbs"], 4), "algorithmic_bytes_per_step": d["bytes"]}
+    e.update({"traffic": pmc_traffic(name), "launches": d["launches"],
+              "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+              "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"])})
+    return e
 
 
-def cpu_baseline(sd, g, runs, beam, max_len):
+def cpu_baseline(sd, g, runs, beam, max_len, end_to_end=True):
     """The oracle in the demo.py shape: one image at a time, fp32 (timing harness shape of reference
     benchmarking/benchmarking.py:95-103).  demo.py does not limit torch's intra-op threads, so the
     default (all host cores) is timed; on many-core hosts that oversubscribes the small ops, so a
     16-thread run is timed too and the faster of the two is reported with its thread count."""
+    import torch
     from on_device_image_captioning_amd import weights as W
     from oracle import expansionnet_ref as R
-    img = W.synth_images(1, g)
+    x = W.synth_images(1, g) if end_to_end else W.synth_features(1, 144, g.final_swin_dim)
 
     def timed(n, k=beam):
         with torch.no_grad():
-            R.beam_search(sd, g, img, [0], SOS, EOS, k, 1, max_len)           # warm-up
+            R.beam_search(sd, g, x, [0], SOS, EOS, k, 1, max_len, end_to_end=end_to_end)           # warm-up
             ts = []
             for _ in range(n):
                 t0 = time.perf_counter()
-                R.beam_search(sd, g, img, [0], SOS, EOS, k, 1, max_len)
+                R.beam_search(sd, g, x, [0], SOS, EOS, k, 1, max_len, end_to_end=end_to_end)
                 ts.append(time.perf_counter() - t0)
         ts.sort()
         return ts[len(ts) // 2], sum(ts) / len(ts)
@@ -182,13 +309,45 @@ def cpu_baseline(sd, g, runs, beam, max_len):
                       f"os.cpu_count()={os.cpu_count()}"}
 
 
+# =================================================================================================
+def selftest_rank(a, world, rank):
+    """Rank plumbing without a GPU: gloo group, barrier, MAX-reduced time, rank 0 prints the line."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * a.steps)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        ranks = [None] * world
+        dist.all_gather_object(ranks, (rank, int(os.environ.get("LOCAL_RANK", "0"))))
+    else:
+        ranks = [(0, 0)]
+    if rank == 0:
+        print(json.dumps({"metric": "selftest", "value": round(a.batch * world * a.steps / dt, 2), "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ranks": ranks, "selftest": True}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; refusing to report a different rank count")
+    if a.cpu_selftest:
+        return selftest_rank(a, world, rank)
+
+    import torch
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
@@ -197,16 +356,27 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" is RCCL on ROCm
 
     from on_device_image_captioning_amd import weights as W
-    from on_device_image_captioning_amd.pipeline import CaptionPipeline, gather_captions
+    from on_device_image_captioning_amd.pipeline import gather_captions, run_shard
     torch.set_grad_enabled(False)
-    model, sd, g = build_model(device, a.precision)
-    pipe = CaptionPipeline(model, a.batch, a.beam, a.max_len, SOS, EOS, use_graphs=not a.no_graphs,
-                           decode_lanes=a.decode_lanes, decode_group=a.decode_group,
-                           encode_lanes=a.encode_lanes)
-    images = W.synth_images(a.batch, g, seed=42 + rank).to(device)         # resident in HBM
+    model, sd, g = build_model(device, a.precision, a.workload)
+    pipe = make_pipe(model, a)
+    e2e = a.workload != "features48"
+    if a.workload == "coco5k":
+        n_distinct = min(64, a.shard)
+        pool = W.synth_images(n_distinct, g, seed=42 + rank).to(device)        # resident in HBM
+        idx = torch.arange(a.shard, device=device) % n_distinct
+        images = pool[:a.batch]
+
+        def fetch(lo, hi):
+            return pool[idx[lo:hi]]
+    elif e2e:
+        images = W.synth_images(a.batch, g, seed=42 + rank).to(device)         # resident in HBM
+    else:
+        images = W.synth_features(a.batch, 144, g.final_swin_dim, seed=42 + rank).to(device)
 
     def finish_one():
         """Captions of the oldest outstanding batch on the host (N > 1: after the RCCL all_gather)."""
@@ -219,6 +389,12 @@ def main():
         """n steps, software-pipelined: while batch i decodes, batch i+1 is already encoding; every
         batch's captions are on the host before run() returns."""
         caps = None
+        if a.workload == "coco5k":
+            for _ in range(n):                 # a step = the rank's whole shard, then ONE gather
+                toks, lens = run_shard(pipe, a.shard, fetch, EOS)
+                caps = gather_captions(toks, lens, a.shard * world) if use_dist else \
+                    gather_captions(toks, lens, a.shard)
+            return caps
         for _ in range(n):
             pipe.submit(images)
             while pipe.full():
@@ -241,23 +417,29 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    per_step = a.shard if a.workload == "coco5k" else a.batch
 
     if rank == 0:
         out = {
-            "metric": "captions/sec end-to-end (Swin-L 384, beam=3) at 1/2/4/8 MI355X",
-            "value": round(a.batch * world * a.steps / dt, 2), "unit": "captions/s", "n_gpus": world,
+            "metric": "captions/sec end-to-end (Swin-L 384, beam=3) at 1/2/4/8 MI355X" if a.workload == "e2e16" else
+                      f"captions/sec ({a.workload})",
+            "value": round(per_step * world * a.steps / dt, 2), "unit": "captions/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.precision if a.precision == "fp32" else "bf16", "data": "synthetic",
-            "config": {"workload": "End_ExpansionNet_v2 end-to-end, Swin-L/384 backbone, batch 16 per GPU, "
-                                   "beam 3, beam_max_seq_len 20 (BASELINE.json configs[2])",
+            "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": WORKLOADS[a.workload]["desc"], "workload_key": a.workload,
                        "batch_per_gpu": a.batch, "beam": a.beam, "beam_max_seq_len": a.max_len,
+                       "images_per_step_per_gpu": per_step,
                        "decoder_steps": pipe.steps, "weights": "synthetic xavier (Philox, seed 0)",
-                       "backbone_precision": a.precision, "captioner_precision": "fp32",
+                       "backbone_precision": a.precision if e2e else None, "encoder_precision": a.precision,
+                       "decoder_precision": "fp32",
                        "hip_graphs": not a.no_graphs, "parallelism": f"image-shard x{world}",
-                       "caption_len_check": min(len(c) for c in caps), "encode_lanes": pipe.E, "decode_lanes": pipe.D, "decode_group_batches": pipe.G,
+                       "caption_len_check": min(len(c) for c in caps), "encode_lanes": pipe.E, "decode_lanes": pipe.D,
+                       "decode_group_batches": pipe.G,
                        "overlap": "encode graph of batch i+1 || beam-search step graphs of earlier batches, one HIP stream each"},
         }
+        if a.workload == "e2e16" and not a.no_parity:
+            out["parity"] = parity_block(model, pipe, a, images, caps[:a.batch], g, device)
         if not a.no_roofline:
             fam = roofline_pass(pipe, images)
             derived = {n: fam.pop(n) for n in list(fam) if n.startswith("swin_attention_block")}
@@ -272,16 +454,85 @@ def main():
                 e["note"] = ("fused-form accounting of SURVEY 8(d): algorithmic FLOPs of qkv Linear + attention core + "
                              "proj Linear per Swin block over the summed durations of those three launches")
                 entries.append(e)
-            out["roofline_note"] = ("achieved = algorithmic FLOPs (2·M·N·K per GEMM) or bytes (q,k,v in + o out per "
-                                    "(window, head)) ÷ Σ HIP-event durations of that kernel family in one instrumented "
-                                    "eager pass of the same step; traffic = measured HBM bytes per launch (average over the family) "
-                                    "from the committed rocprofv3 PMC passes, profiles/r01_pmc_traffic.json")
+            src = (_PMC or {}).get("_meta", {})
+            out["roofline_note"] = ("achieved = algorithmic FLOPs (2·M·N·K per GEMM) or bytes (DESIGN.md §4 per family) ÷ Σ "
+                                    "HIP-event durations of that kernel family in one instrumented eager pass of the same "
+                                    "step; traffic = measured HBM bytes per launch (average over the family) from the "
+                                    "committed rocprofv3 PMC passes, " + os.path.relpath(PMC_FILE, ROOT))
+            out["traffic_source"] = {"file": os.path.relpath(PMC_FILE, ROOT), "kernel_source_hash_then": src.get("kernel_source_hash"),
+                                     "kernel_source_hash_now": kernel_source_hash(),
+                                     "stale": src.get("kernel_source_hash") != kernel_source_hash()}
             out["kernels"] = entries
+        if world == 1 and a.workload == "e2e16" and not a.no_fp32 and a.precision != "fp32":
+            out.update(fp32_block(model, a, images))
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, g, a.cpu_runs, a.beam, a.max_len)
+            out["cpu_baseline"] = cpu_baseline(sd, g, a.cpu_runs, a.beam, min(a.max_len, 20), end_to_end=e2e)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def parity_block(model, pipe, a, images, last_caps, g, device):
+    """(1) the pipelined captions of the last timed batch equal the un-pipelined direct call (a lane / hand-off
+    race at the bench shape would show here); (2) CIDEr-D of this mode's captions against the fp32 mode's."""
+    import torch
+    from on_device_image_captioning_amd import weights as W
+    from on_device_image_captioning_amd.evaluation import caption_agreement
+    toks, _ = model(enc_x=images, enc_x_num_pads=[0] * a.batch, mode="beam_search", beam_size=a.beam,
+                    how_many_outputs=1, beam_max_seq_len=a.max_len, sample_or_max="max", sos_idx=SOS, eos_idx=EOS)
+    direct = [t[0] for t in toks]
+    blk = {"pipeline_equals_direct_call": direct == last_caps}
+    if not blk["pipeline_equals_direct_call"]:
+        raise SystemExit("bench.py: pipelined captions differ from the direct call — refusing to report a throughput")
+    if a.cider_images > 0 and a.precision != "fp32":
+        nb = (a.cider_images + a.batch - 1) // a.batch
+        batches = [W.synth_images(a.batch, g, seed=2000 + i).to(device) for i in range(nb)]
+
+        def all_caps(p):
+            caps = []
+            for b in batches:
+                p.submit(b)
+                while p.full():
+                    caps += p.collect()
+            while p.outstanding():
+                caps += p.collect()
+            return caps
+        mine = all_caps(pipe)
+        model.set_precision("fp32")
+        ref_pipe = make_pipe(model, a)
+        ref = all_caps(ref_pipe)
+        del ref_pipe
+        model.set_precision(a.precision)
+        torch.cuda.empty_cache()
+        blk["cider_d_vs_fp32_captions"] = caption_agreement(mine, ref)
+        blk["note"] = ("fp32-mode captions equal the reference implementation's token for token (tests/golden); with random "
+                       "(xavier) weights the top-1/top-2 log-prob margins are below bf16 resolution, so bf16 captions "
+                       "diverge after a prefix (DESIGN.md §3); parity on real weights is unpinned (rf_model.pth absent)")
+    return blk
+
+
+def fp32_block(model, a, images):
+    """The bit-exact mode timed in the same run, same workload, same pipeline structure."""
+    import torch
+    model.set_precision("fp32")
+    pipe = make_pipe(model, a)
+
+    def run(n):
+        for _ in range(n):
+            pipe.submit(images)
+            while pipe.full():
+                pipe.collect()
+        while pipe.outstanding():
+            pipe.collect()
+    run(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(a.fp32_steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    model.set_precision(a.precision)
+    return {"fp32_value": round(a.batch * a.fp32_steps / dt, 2), "fp32_ms_per_step": round(1e3 * dt / a.fp32_steps, 3),
+            "fp32_steps": a.fp32_steps}
 
 
 if __name__ == "__main__":

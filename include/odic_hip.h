@@ -40,7 +40,7 @@ extern "C" {
 #define ODIC_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ODIC_ABI_VERSION 5
+#define ODIC_ABI_VERSION 6
 int odic_abi_version(void);
 
 /* Human-readable build string ("gfx950 hipcc ..."), static storage. */
@@ -252,13 +252,29 @@ typedef struct odic_beam_state {
   int32_t* pos; int32_t* done;
   int32_t* ctr;      /* int32 scalar, zero before the first call: inter-block arrival counter */
 } odic_beam_state;
+/*   Limits: beams <= 16, 2 <= T <= 128 (per-token log-probs are staged in LDS), n_img <= 32767 (the
+ *   arrival counter packs {arrivals, still-growing images} into one int32): ODIC_EINVAL otherwise. */
 int odic_beam_step(const float* cand_val, const int32_t* cand_idx, const odic_beam_state* st,
                    int32_t n_img, int32_t beams, int32_t T, int64_t eos_idx, void* stream);
+
+/* Initial state of a search (captioning_model.py:117-125): tokens[:, :, 0] = sos, logprobs[:, :, 0] = 0,
+ * next_tok = sos, row_valid = 1, *pos = *done = *ctr = 0.  One launch instead of six fills on the
+ * latency-bound decode stream. */
+int odic_beam_reset(const odic_beam_state* st, int32_t n_img, int32_t beams, int32_t T, int64_t sos_idx,
+                    void* stream);
 
 /* Final selection (captioning_model.py:225-241): score = cumul / n_elem, descending order per
  * image → order int32 [n_img, beams], score fp32 [n_img, beams]. */
 int odic_beam_finalize(const odic_beam_state* st, int32_t* order, float* score, int32_t n_img,
                        int32_t beams, void* stream);
+
+/* odic_beam_finalize + the best caption of every image in the fixed-shape form the multi-GPU gather
+ * ships (captioning_model.py:225-241 with how_many_outputs = 1; test.py:216-224 takes output_words[i][0]):
+ * out_tok int32 [n_img, T] = tokens of the best beam, positions >= its length filled with pad_idx;
+ * out_len int32 [n_img] = its length (SOS and EOS included). */
+int odic_beam_finalize_best(const odic_beam_state* st, int32_t* order, float* score, int32_t* out_tok,
+                            int32_t* out_len, int32_t n_img, int32_t beams, int32_t T, int32_t pad_idx,
+                            void* stream);
 
 #ifdef __cplusplus
 }

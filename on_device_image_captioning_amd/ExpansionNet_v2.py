@@ -43,7 +43,8 @@ class ExpansionNet_v2(CaptioningModel):
 
     def _captioner_engine(self):
         if self._eng_cache is None:
-            self._eng_cache = _engine.CaptionerEngine(self.state_dict(), self.geometry, self._device(), self.precision)
+            self._eng_cache = _engine.CaptionerEngine(self.state_dict(), self.geometry, self._device(),
+                                                          self.encoder_precision or self.precision)
         return self._eng_cache
 
     def _enc_lens(self, n, S, enc_input_num_pads):

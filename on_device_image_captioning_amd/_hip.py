@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libodic_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _ERR = {-1: "ODIC_EINVAL (bad shape / alignment / enum)", -2: "ODIC_ENULL (required pointer is NULL)",
         -3: "ODIC_EUNSUPPORTED"}
@@ -63,6 +63,8 @@ _SIGNATURES = {
     "odic_topk_rows": (C.c_int, [_P, _I64, _P, _P, _I32, _I32, _I32, _P]),
     "odic_beam_step": (C.c_int, [_P, _P, C.POINTER(BeamState), _I32, _I32, _I32, _I64, _P]),
     "odic_beam_finalize": (C.c_int, [C.POINTER(BeamState), _P, _P, _I32, _I32, _P]),
+    "odic_beam_finalize_best": (C.c_int, [C.POINTER(BeamState), _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "odic_beam_reset": (C.c_int, [C.POINTER(BeamState), _I32, _I32, _I32, _I64, _P]),
 }
 
 #: every symbol include/odic_hip.h declares

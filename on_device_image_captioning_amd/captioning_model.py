@@ -35,19 +35,22 @@ class CaptioningModel(nn.Module):
         self.apply_log_softmax = apply_log_softmax
         self._eng_cache = None
         self.precision = "fp32"
+        self.encoder_precision = None       # None = follow `precision`
 
     # ------------------------------------------------------------------ engine cache plumbing
     def check_required_attributes(self):
         if self.rank is None:
             raise NotImplementedError("Subclass must assign the rank integer according to the GPU group")
 
-    def set_precision(self, precision: str) -> "CaptioningModel":
+    def set_precision(self, precision: str, encoder_precision: Optional[str] = None) -> "CaptioningModel":
         """'fp32' (default; exact-fp32 MFMA, parity mode) or 'bf16' (backbone GEMMs + window
-        attention in bf16 with fp32 accumulation and an fp32 residual stream)."""
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
-        if precision != self.precision:
-            self.precision = precision
+        attention in bf16 with fp32 accumulation and an fp32 residual stream; expansion-encoder
+        products in bf16 too unless `encoder_precision='fp32'`).  The decoder is always fp32."""
+        for p in (precision, encoder_precision or precision):
+            if p not in ("fp32", "bf16"):
+                raise ValueError("precision must be 'fp32' or 'bf16'")
+        if (precision, encoder_precision) != (self.precision, self.encoder_precision):
+            self.precision, self.encoder_precision = precision, encoder_precision
             self._eng_cache = None
         return self
 

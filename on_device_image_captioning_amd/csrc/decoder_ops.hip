@@ -603,6 +603,38 @@ __global__ void beam_finalize_kernel(const float* cumul, const int* n_elem, int*
   }
 }
 
+// odic_beam_finalize + emission of the best caption (EOS-padded int32 row + length): one 64-lane block per image
+__global__ __launch_bounds__(64) void beam_finalize_best_kernel(const float* cumul, const int* n_elem,
+                                                                const long long* tok, int* order, float* score,
+                                                                int* out_tok, int* out_len, int k, int T, int pad) {
+  __shared__ int s_best;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (lane == 0) {
+    float sc[MAX_K];
+    for (int j = 0; j < k; ++j) { sc[j] = cumul[b * k + j] / (float)n_elem[b * k + j]; score[b * k + j] = sc[j]; }
+    for (int r = 0; r < k; ++r) {
+      int bi = 0; float bv = -INFINITY;
+      for (int j = 0; j < k; ++j) if (sc[j] > bv) { bv = sc[j]; bi = j; }
+      sc[bi] = -INFINITY;
+      order[b * k + r] = bi;
+      if (r == 0) s_best = bi;
+    }
+  }
+  __syncthreads();
+  const int best = s_best;
+  const int len = n_elem[b * k + best];
+  const long long* src = tok + ((long)b * k + best) * T;
+  for (int j = lane; j < T; j += 64) out_tok[(long)b * T + j] = j < len ? (int)src[j] : pad;
+  if (lane == 0) out_len[b] = len;
+}
+
+__global__ void beam_reset_kernel(long long* tok, float* lp, int* row_valid, long long* next_tok, int* pos,
+                                  int* done, int* ctr, int N, int T, long long sos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { tok[(long)i * T] = sos; lp[(long)i * T] = 0.f; row_valid[i] = 1; next_tok[i] = sos; }
+  if (i == 0) { *pos = 0; *done = 0; *ctr = 0; }
+}
+
 }  // namespace
 
 extern "C" int odic_dec_embed(const int64_t* tokens, const float* embed, const float* pos_table,
@@ -737,11 +769,11 @@ extern "C" int odic_logsoftmax_topk(const float* logits, int64_t ldl, float* log
 extern "C" int odic_beam_step(const float* cand_val, const int32_t* cand_idx, const odic_beam_state* st,
                               int32_t n_img, int32_t beams, int32_t T, int64_t eos_idx, void* stream) {
   if (!cand_val || !cand_idx || !st) return ODIC_ENULL;
-  if (n_img <= 0 || beams <= 0 || beams > MAX_K || T <= 1) return ODIC_EINVAL;
+  // T: k x (t+1) per-token log-probs are staged in s_lpm[MAX_K][MAX_T]; n_img: `alive << 16` in the counter
+  if (n_img <= 0 || beams <= 0 || beams > MAX_K || T <= 1 || T > MAX_T || n_img > 32767) return ODIC_EINVAL;
   if (!st->tokens || !st->logprobs || !st->anc || !st->cumul || !st->n_elem || !st->has_eos || !st->row_valid ||
       !st->next_tok || !st->pos || !st->done || !st->ctr)
     return ODIC_ENULL;
-  if (n_img >= 65536) return ODIC_EINVAL;
   BeamParams p;
   p.cand_val = cand_val; p.cand_idx = cand_idx;
   p.tok = (long long*)st->tokens; p.lp = st->logprobs; p.anc = st->anc;
@@ -758,5 +790,29 @@ extern "C" int odic_beam_finalize(const odic_beam_state* st, int32_t* order, flo
   if (n_img <= 0 || beams <= 0 || beams > MAX_K) return ODIC_EINVAL;
   hipLaunchKernelGGL(beam_finalize_kernel, dim3((n_img + 63) / 64), dim3(64), 0, (hipStream_t)stream, st->cumul,
                      st->n_elem, order, score, n_img, beams);
+  return odic_launch_status();
+}
+
+extern "C" int odic_beam_finalize_best(const odic_beam_state* st, int32_t* order, float* score, int32_t* out_tok,
+                                       int32_t* out_len, int32_t n_img, int32_t beams, int32_t T, int32_t pad_idx,
+                                       void* stream) {
+  if (!st || !order || !score || !out_tok || !out_len) return ODIC_ENULL;
+  if (!st->tokens || !st->cumul || !st->n_elem) return ODIC_ENULL;
+  if (n_img <= 0 || beams <= 0 || beams > MAX_K || T <= 0) return ODIC_EINVAL;
+  hipLaunchKernelGGL(beam_finalize_best_kernel, dim3(n_img), dim3(64), 0, (hipStream_t)stream, st->cumul, st->n_elem,
+                     (const long long*)st->tokens, order, score, out_tok, out_len, beams, T, pad_idx);
+  return odic_launch_status();
+}
+
+extern "C" int odic_beam_reset(const odic_beam_state* st, int32_t n_img, int32_t beams, int32_t T, int64_t sos_idx,
+                               void* stream) {
+  if (!st) return ODIC_ENULL;
+  if (!st->tokens || !st->logprobs || !st->row_valid || !st->next_tok || !st->pos || !st->done || !st->ctr)
+    return ODIC_ENULL;
+  if (n_img <= 0 || beams <= 0 || beams > MAX_K || T <= 0) return ODIC_EINVAL;
+  const int N = n_img * beams;
+  hipLaunchKernelGGL(beam_reset_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (long long*)st->tokens, st->logprobs, st->row_valid, (long long*)st->next_tok, st->pos, st->done,
+                     st->ctr, N, T, (long long)sos_idx);
   return odic_launch_status();
 }

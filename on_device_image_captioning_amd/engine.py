@@ -283,10 +283,12 @@ class CaptionerEngine:
         a = mem.reshape(B * S, d)
         if not a.is_contiguous():
             a = a.contiguous()
-        w = self.kv_w if a.dtype == self.kv_w.dtype else self.kv_w32
-        if a.dtype != w.dtype:
-            a = a.to(w.dtype)
-        ops.gemm(a, w, self.kv_b, out=out, M=B * S, N=n, K=d, lda=d, ldw=d, ldc=n)
+        # bf16 mode: the product runs on the bf16 MFMA GEMM whatever dtype the caller holds the memory in, so
+        # the direct beam_search call and CaptionPipeline (which feeds the bf16 LayerNorm output) see
+        # bit-identical K/V: round-to-nearest-even of the same fp32 values either way.
+        if a.dtype != self.kv_w.dtype:
+            a = self._as_operand(a, B * S, d, d)
+        ops.gemm(a, self.kv_w, self.kv_b, out=out, M=B * S, N=n, K=d, lda=d, ldw=d, ldc=n)
         return out
 
     # ------------------------------------------------------------------------------------------
@@ -303,7 +305,9 @@ class CaptionerEngine:
         d, L, N = g.d_model, g.N_dec, st.N
         ld = L * d
         ops.dec_embed(st.next_tok, self.embed, self.pos_table, st.pos, st.ycat, ld, N, d, math.sqrt(d))
-        fuse = self.fuse_ln
+        # the folded-LayerNorm form lives in the skinny-M kernel (M <= 192 rows, gemm_f32.hip); wider
+        # searches (batch 64 x beam 5, decode groups) take the LayerNorm + GEMM pair
+        fuse = self.fuse_ln and N <= 192
         eps = 1e-5
 
         def ln_gemm(x, ldx, nw, nb, W, b, folded, **kw):

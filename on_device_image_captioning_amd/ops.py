@@ -63,6 +63,16 @@ class _timed:
         return False
 
 
+#: position index of the decoder step being launched, set by the host loop while a profile is active
+#: (the kernels read *pos from device memory; the host needs it only to price the step's cache reads)
+_STEP_T: Optional[int] = None
+
+
+def set_step_hint(t: Optional[int]) -> None:
+    global _STEP_T
+    _STEP_T = t
+
+
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -301,7 +311,10 @@ def stcexp_normalize(z: torch.Tensor, enc_len: torch.Tensor, group_meta: torch.T
     """Outputs may be fp32 or bf16 and wider than (S / nq): padding columns are zero-filled."""
     _need_cuda(z, enc_len, group_meta, pos_fw, neg_fw, pos_bw, neg_bw, colsum_ws)
     B, nq, S = z.shape
-    with _timed("stcexp_normalize", 0.0, 0.0):
+    # algorithmic bytes: z read once, the four normalised weight tables written once (incl. their zero K padding)
+    osz = pos_fw.element_size()
+    with _timed("stcexp_normalize", 6.0 * B * nq * S,
+                B * nq * S * 4.0 + 2.0 * B * nq * pos_fw.shape[-1] * osz + 2.0 * B * S * pos_bw.shape[-1] * osz):
         _hip.check(_hip.load().odic_stcexp_normalize(_p(z), _p(enc_len), _p(group_meta), ngroups, _p(pos_fw),
                                                      _p(neg_fw), pos_fw.shape[-1], _p(pos_bw), _p(neg_bw),
                                                      pos_bw.shape[-1], _p(colsum_ws), B, nq, S, eps,
@@ -310,7 +323,7 @@ def stcexp_normalize(z: torch.Tensor, enc_len: torch.Tensor, group_meta: torch.T
 
 def selector_mix(x, ldx, sel_pre, lds, a, lda, b, ldb, out, ldo, M, d) -> None:
     _need_cuda(x, sel_pre, a, b, out)
-    with _timed("selector_mix", 0.0, 0.0):
+    with _timed("selector_mix", 6.0 * M * d, 5.0 * M * d * 4):     # x, selector, A', B' in; y out
         _hip.check(_hip.load().odic_selector_mix(_p(x), ldx, _p(sel_pre), lds, _p(a), lda, _p(b), ldb, _p(out), ldo,
                                                  M, d, _stream()), "odic_selector_mix")
 
@@ -318,7 +331,7 @@ def selector_mix(x, ldx, sel_pre, lds, a, lda, b, ldb, out, ldo, M, d) -> None:
 # ----------------------------------------------------------------------------------------------
 def dec_embed(tokens, embed, pos_table, pos, y, ldy, N, d, scale) -> None:
     _need_cuda(tokens, embed, pos_table, pos, y)
-    with _timed("dec_embed", 0.0, 0.0):
+    with _timed("dec_embed", 2.0 * N * d, N * (8.0 + 2 * d * 4) + d * 4):     # token id, embedding row in, y row out, one pos row
         _hip.check(_hip.load().odic_dec_embed(_p(tokens), _p(embed), _p(pos_table), _p(pos), _p(y), ldy, N, d, scale,
                                               _stream()), "odic_dec_embed")
 
@@ -326,7 +339,15 @@ def dec_embed(tokens, embed, pos_table, pos, y, ldy, N, d, scale) -> None:
 def dynexp_step(lin, ldlin, qexp, bexp, cond_c, key_c, va_c, vb_c, afull_c, bfull_c, qk_c, anc, row_valid, pos,
                 y_in, ldy_in, y, ldy, scratch, N, T, d, E, eps=1e-9) -> None:
     _need_cuda(lin, qexp, bexp, cond_c, key_c, va_c, vb_c, afull_c, bfull_c, qk_c, anc, row_valid, pos, y_in, y)
-    with _timed("dynexp_step", 0.0, 0.0):
+    # algorithmic bytes of one incremental step at position t (layers.py:152-204 on the newest row only):
+    # in  lin [N,5d], y_in; history of positions <= t through the ancestor table: cond, key [d each],
+    #     class_a/b+bias [E·d each], query·key [E];   out  the same cache rows for position t, y.
+    # t = the host's step hint, else the mean position of a T-long search.
+    t = _STEP_T if _STEP_T is not None else (T - 1) / 2.0
+    per_pos = (2 * d + 2 * E * d + E) * 4.0
+    nbytes = N * ((5 * d + 2 * d) * 4.0 + (t + 1) * per_pos + per_pos + 2 * d * 4.0 + (t + 1) * 4.0)
+    flops = N * (t + 1) * (2.0 * 2 * d + 2.0 * 2 * E * d + 8.0 * E)
+    with _timed("dynexp_step", flops, nbytes):
         _hip.check(_hip.load().odic_dynexp_step(_p(lin), ldlin, _p(qexp), _p(bexp), _p(cond_c), _p(key_c), _p(va_c),
                                                 _p(vb_c), _p(afull_c), _p(bfull_c), _p(qk_c), _p(anc), _p(row_valid),
                                                 _p(pos), _p(y_in), ldy_in, _p(y), ldy, _p(scratch), N, T, d, E, eps,
@@ -336,7 +357,8 @@ def dynexp_step(lin, ldlin, qexp, bexp, cond_c, key_c, va_c, vb_c, afull_c, bful
 
 def cross_attn_step(q, ldq, kv, ldkv, koff, voff, enc_len, row_valid, out, ldo, N, n_img, S, d, heads) -> None:
     _need_cuda(q, kv, enc_len, row_valid, out)
-    with _timed("cross_attn_step", 0.0, 0.0):
+    # q and out rows per sequence, K and V of the S encoder tokens ONCE per image (shared by its beams)
+    with _timed("cross_attn_step", 4.0 * N * S * d, (2.0 * N * d + 2.0 * n_img * S * d) * 4):
         _hip.check(_hip.load().odic_cross_attn_step(_p(q), ldq, _p(kv), ldkv, koff, voff, _p(enc_len), _p(row_valid),
                                                     _p(out), ldo, N, n_img, S, d, heads, _stream()),
                    "odic_cross_attn_step")
@@ -344,7 +366,7 @@ def cross_attn_step(q, ldq, kv, ldkv, koff, voff, enc_len, row_valid, out, ldo, 
 
 def logsoftmax_topk(logits, ldl, logp_out, ldp, top_val, top_idx, N, V, k) -> None:
     _need_cuda(logits, logp_out, top_val, top_idx)
-    with _timed("logsoftmax_topk", 0.0, 0.0):
+    with _timed("logsoftmax_topk", 4.0 * N * V, N * V * 4.0 * (2 if logp_out is not None else 1) + N * k * 8.0):
         _hip.check(_hip.load().odic_logsoftmax_topk(_p(logits), ldl, _p(logp_out), ldp, _p(top_val), _p(top_idx), N, V,
                                                     k, _stream()), "odic_logsoftmax_topk")
 
@@ -369,12 +391,27 @@ def topk_rows(logp: torch.Tensor, top_val: torch.Tensor, top_idx: torch.Tensor, 
 
 
 def beam_step(cand_val, cand_idx, state: "_hip.BeamState", n_img, beams, T, eos_idx) -> None:
-    with _timed("beam_step", 0.0, 0.0):
+    # k² candidates in, the k prefixes (token int64, log-prob, ancestor) of t+1 positions read and re-written
+    t = _STEP_T if _STEP_T is not None else (T - 1) / 2.0
+    with _timed("beam_step", 0.0, n_img * (beams * beams * 8.0 + 2.0 * beams * (t + 1) * 16.0 + beams * 32.0)):
         _hip.check(_hip.load().odic_beam_step(_p(cand_val), _p(cand_idx), C.byref(state), n_img, beams, T, eos_idx,
                                               _stream()), "odic_beam_step")
 
 
 def beam_finalize(state: "_hip.BeamState", order, score, n_img, beams) -> None:
-    with _timed("beam_finalize", 0.0, 0.0):
+    with _timed("beam_finalize", 0.0, n_img * beams * 16.0):
         _hip.check(_hip.load().odic_beam_finalize(C.byref(state), _p(order), _p(score), n_img, beams, _stream()),
                    "odic_beam_finalize")
+
+
+def beam_finalize_best(state: "_hip.BeamState", order, score, out_tok, out_len, n_img, beams, T, pad_idx) -> None:
+    """Final ranking + the best caption per image as an int32 [n_img, T] row padded with `pad_idx` and its length."""
+    _need_cuda(order, score, out_tok, out_len)
+    with _timed("beam_finalize", 0.0, n_img * (beams * 8.0 + T * 12.0)):
+        _hip.check(_hip.load().odic_beam_finalize_best(C.byref(state), _p(order), _p(score), _p(out_tok), _p(out_len),
+                                                       n_img, beams, T, pad_idx, _stream()), "odic_beam_finalize_best")
+
+
+def beam_reset(state: "_hip.BeamState", n_img, beams, T, sos_idx) -> None:
+    with _timed("beam_reset", 0.0, n_img * beams * 28.0):
+        _hip.check(_hip.load().odic_beam_reset(C.byref(state), n_img, beams, T, sos_idx, _stream()), "odic_beam_reset")

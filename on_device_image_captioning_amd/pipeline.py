@@ -41,9 +41,11 @@ class CaptionPipeline:
 
     def __init__(self, model: CaptioningModel, batch: int, beam_size: int, max_seq_len: int, sos_idx: int,
                  eos_idx: int, use_graphs: bool = True, done_poll: int = 0, decode_lanes: int = 2,
-                 streams=None, decode_group: int = 1, encode_lanes: int = 1):
+                 streams=None, decode_group: int = 1, encode_lanes: int = 1, feat_len: int = 144):
         """done_poll = 0: never look at the `done` flag (fixed work per batch — benchmark mode with
-        weights that never emit EOS); n > 0: host checks every n steps and stops early."""
+        weights that never emit EOS); n > 0: host checks every n steps and stops early.
+        `model` is an End_ExpansionNet_v2 (inputs: images [B,3,H,W]) or a features-only ExpansionNet_v2
+        (inputs: features [B, feat_len, F] + per-sample trailing pad counts, ExpansionNet_v2.py:50-70)."""
         self.model, self.B, self.k = model, batch, beam_size
         self.steps = max(1, max_seq_len - 1)
         self.T = self.steps + 1
@@ -55,20 +57,30 @@ class CaptionPipeline:
         self.NB = self.G * batch                                   # images per search launch
         self.RG = self.D + 1                                       # result ring, in groups
         self.R = self.RG * self.G                                  # batches that may be outstanding (upper bound)
-        swin, cap = model._engines()
+        if hasattr(model, "swin_transf"):
+            swin, cap = model._engines()
+        else:
+            swin, cap = None, model._captioner_engine()
         self.swin, self.cap = swin, cap
         g, dv = cap.g, cap.device
         self.device = dv
-        self.imgs = [torch.zeros(batch, g.swin_in_chans, g.swin_img_size, g.swin_img_size, dtype=torch.float32,
-                                 device=dv) for _ in range(self.E)]
-        S = g.stage_res(len(g.swin_depths) - 1) ** 2
-        self.enc_len = torch.full((batch,), S, dtype=torch.int32, device=dv)
-        self.enc_len_grp = torch.full((self.NB,), S, dtype=torch.int32, device=dv)
+        if swin is not None:
+            in_shape = (batch, g.swin_in_chans, g.swin_img_size, g.swin_img_size)
+            S = g.stage_res(len(g.swin_depths) - 1) ** 2
+        else:
+            in_shape = (batch, feat_len, g.final_swin_dim)
+            S = feat_len
+        self.S = S
+        self.imgs = [torch.zeros(*in_shape, dtype=torch.float32, device=dv) for _ in range(self.E)]
+        # encoder lengths: one buffer per encode lane (read by its graph) + one per decode lane (its group)
+        self.enc_lens = [torch.full((batch,), S, dtype=torch.int32, device=dv) for _ in range(self.E)]
+        self.enc_len_grps = [torch.full((self.NB,), S, dtype=torch.int32, device=dv) for _ in range(self.D)]
+        self.host_len_in = [torch.full((batch,), S, dtype=torch.int32).pin_memory() for _ in range(self.E)]
         nkv = 2 * g.N_dec * g.d_model
         self.kv_stages = [torch.empty(batch, S, nkv, dtype=torch.float32, device=dv)    # written by the encode graphs
                           for _ in range(self.E)]
         self.kv = [torch.empty(self.NB, S, nkv, dtype=torch.float32, device=dv) for _ in range(self.D)]
-        self.states = [cap.new_state(self.NB, beam_size, self.T, self.kv[l], self.enc_len_grp)
+        self.states = [cap.new_state(self.NB, beam_size, self.T, self.kv[l], self.enc_len_grps[l])
                        for l in range(self.D)]
         self.order = [torch.empty(self.NB, beam_size, dtype=torch.int32, device=dv) for _ in range(self.D)]
         self.score = [torch.empty(self.NB, beam_size, dtype=torch.float32, device=dv) for _ in range(self.D)]
@@ -80,7 +92,8 @@ class CaptionPipeline:
             self.s_dec = [torch.cuda.Stream(device=dv) for _ in range(self.D)]
         self.ev_enc = [torch.cuda.Event() for _ in range(self.E)]
         self.ev_kv_taken = [torch.cuda.Event() for _ in range(self.E)]
-        for ev in self.ev_kv_taken:
+        self.ev_len_up = [torch.cuda.Event() for _ in range(self.E)]      # pinned length buffer free to rewrite
+        for ev in self.ev_kv_taken + self.ev_len_up:
             ev.record()
         # results ring (device, one slot per group) + pinned host mirrors
         self.out_tok = [torch.zeros(self.NB, self.T, dtype=torch.int32, device=dv) for _ in range(self.RG)]
@@ -88,6 +101,9 @@ class CaptionPipeline:
         self.host_tok = [torch.zeros(self.NB, self.T, dtype=torch.int32).pin_memory() for _ in range(self.RG)]
         self.host_len = [torch.zeros(self.NB, dtype=torch.int32).pin_memory() for _ in range(self.RG)]
         self.ev_done = [torch.cuda.Event() for _ in range(self.RG)]
+        self.ev_res_free = [torch.cuda.Event() for _ in range(self.RG)]   # device-side consumers are done with the slot
+        for ev in self.ev_res_free:
+            ev.record()
         self._submitted = self._collected = 0
         self._gi = 0                 # index of the group being filled
         self._gfill = 0              # batches already staged into it
@@ -120,24 +136,19 @@ class CaptionPipeline:
 
     # -- the captured regions -------------------------------------------------------------------
     def _encode(self, e: int = 0) -> None:
-        feats = self.swin.forward(self.imgs[e], out_dtype=self.cap.cdt)
+        feats = self.swin.forward(self.imgs[e], out_dtype=self.cap.cdt) if self.swin is not None else self.imgs[e]
         if self.cap.cdt == torch.bfloat16:
-            _, mem16 = self.cap.encode(feats, self.enc_len, want_bf16_mem=True)
+            _, mem16 = self.cap.encode(feats, self.enc_lens[e], want_bf16_mem=True)
             self.cap.project_kv(mem16, out=self.kv_stages[e])
         else:
-            self.cap.project_kv(self.cap.encode(feats, self.enc_len), out=self.kv_stages[e])
+            self.cap.project_kv(self.cap.encode(feats, self.enc_lens[e]), out=self.kv_stages[e])
 
     def _step(self, lane: int) -> None:
         self.cap.beam_step(self.states[lane], self.eos)
 
     def _reset(self, lane: int) -> None:
         st = self.states[lane]
-        st.tokens[:, :, 0] = self.sos
-        st.logprobs[:, :, 0] = 0.0
-        st.next_tok.fill_(self.sos)
-        st.row_valid.fill_(1)
-        st.pos.zero_()
-        st.done.zero_()
+        ops.beam_reset(st.beam_state, st.n_img, st.beams, st.T, self.sos)
 
     def _capture(self) -> None:
         torch.cuda.synchronize()
@@ -163,8 +174,11 @@ class CaptionPipeline:
         torch.cuda.synchronize()
 
     # -- public ---------------------------------------------------------------------------------
-    def submit(self, images: torch.Tensor) -> None:
-        """Enqueue one batch; never blocks the host (unless done_poll > 0)."""
+    def submit(self, images: torch.Tensor, enc_num_pads: Optional[Sequence[int]] = None) -> None:
+        """Enqueue one batch; never blocks the host (unless done_poll > 0).  `enc_num_pads` (features-only
+        model): trailing padded positions per sample, as the reference's enc_x_num_pads."""
+        if enc_num_pads is not None and self.swin is not None and any(int(p) for p in enc_num_pads):
+            raise AssertionError("End to End case have no padding")
         if self.full():
             raise RuntimeError(f"result ring full ({self.outstanding()} batches outstanding); call collect() first")
         gi, gpos = self._gi, self._gfill
@@ -175,7 +189,19 @@ class CaptionPipeline:
         with torch.cuda.stream(se):
             se.wait_stream(cur)                                  # `images` may have been produced there
             se.wait_event(self.ev_kv_taken[e])                   # this lane's previous K/V hand-off finished
+            if images.is_cuda:
+                images.record_stream(se)                         # the caller may drop `images` right after submit()
             self.imgs[e].copy_(images, non_blocking=True)
+            if self.swin is None:                                # per-sample encoder lengths ride along
+                hl = self.host_len_in[e]
+                pads = [0] * self.B if enc_num_pads is None else [int(p) for p in enc_num_pads]
+                if len(pads) != self.B:
+                    raise RuntimeError(f"expected {self.B} pad counts, got {len(pads)}")
+                self._len_host_free(e)
+                for i, pz in enumerate(pads):
+                    hl[i] = self.S - pz
+                self.enc_lens[e].copy_(hl, non_blocking=True)
+                self.ev_len_up[e].record()
             if self.g_encs[e] is not None:
                 self.g_encs[e].replay()
             else:
@@ -185,12 +211,17 @@ class CaptionPipeline:
         with torch.cuda.stream(sd):
             sd.wait_event(self.ev_enc[e])
             self.kv[lane][gpos * self.B:(gpos + 1) * self.B].copy_(self.kv_stages[e])
+            if self.swin is None:
+                self.enc_len_grps[lane][gpos * self.B:(gpos + 1) * self.B].copy_(self.enc_lens[e])
             self.ev_kv_taken[e].record()
         self._where.append((gi, gpos))
         self._submitted += 1
         self._gfill += 1
         if self._gfill == self.G:
             self._launch_group()
+
+    def _len_host_free(self, e: int) -> None:
+        self.ev_len_up[e].synchronize()                          # the previous upload from this pinned buffer is done
 
     def flush(self) -> None:
         """Search a partially filled group now (its empty positions repeat the last staged batch)."""
@@ -204,33 +235,28 @@ class CaptionPipeline:
         with torch.cuda.stream(self.s_dec[lane]):
             for p in range(filled, self.G):
                 self.kv[lane][p * self.B:(p + 1) * self.B].copy_(self.kv[lane][(filled - 1) * self.B:filled * self.B])
+                if self.swin is None:
+                    self.enc_len_grps[lane][p * self.B:(p + 1) * self.B].copy_(
+                        self.enc_len_grps[lane][(filled - 1) * self.B:filled * self.B])
             self._reset(lane)
             for t in range(self.steps):
                 if self.g_step[lane] is not None:
                     self.g_step[lane].replay()
                 else:
+                    ops.set_step_hint(t)                         # prices the step's cache reads in a profile pass
                     self._step(lane)
+                    ops.set_step_hint(None)
                 if self.done_poll and t >= 1 and (t + 1) % self.done_poll == 0 and t + 1 < self.steps \
                         and int(st.done.item()):
                     break
-            ops.beam_finalize(st.beam_state, self.order[lane], self.score[lane], self.NB, self.k)
-            toks, lens = self._best_tokens(lane)
-            self.out_tok[gslot].copy_(toks)
-            self.out_len[gslot].copy_(lens)
+            self.s_dec[lane].wait_event(self.ev_res_free[gslot])   # collect_device() readers of the slot's last use
+            ops.beam_finalize_best(st.beam_state, self.order[lane], self.score[lane], self.out_tok[gslot],
+                                   self.out_len[gslot], self.NB, self.k, self.T, self.eos)
             self.host_tok[gslot].copy_(self.out_tok[gslot], non_blocking=True)
             self.host_len[gslot].copy_(self.out_len[gslot], non_blocking=True)
             self.ev_done[gslot].record()
         self._gi += 1
         self._gfill = 0
-
-    def _best_tokens(self, lane: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        st = self.states[lane]
-        best = self.order[lane][:, 0].long()
-        bidx = torch.arange(self.NB, device=best.device)
-        toks = st.tokens[bidx, best]                                       # [G·B, T]
-        lens = st.n_elem.view(self.NB, self.k)[bidx, best]
-        pad = torch.arange(self.T, device=best.device)[None, :] >= lens[:, None]
-        return toks.masked_fill(pad, self.eos), lens
 
     def outstanding(self) -> int:
         return self._submitted - self._collected
@@ -252,11 +278,14 @@ class CaptionPipeline:
         batch, ordered after its decode on the CURRENT stream (for a following collective)."""
         gi, gpos = self._oldest()
         gslot = gi % self.RG
-        torch.cuda.current_stream().wait_event(self.ev_done[gslot])
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.ev_done[gslot])
         self._where.pop(0)
         self._collected += 1
         rows = slice(gpos * self.B, (gpos + 1) * self.B)
-        return self.out_tok[gslot][rows], self.out_len[gslot][rows]
+        toks, lens = self.out_tok[gslot][rows].clone(), self.out_len[gslot][rows].clone()
+        self.ev_res_free[gslot].record(cur)                      # the ring slot may be rewritten after these copies
+        return toks, lens
 
     def collect(self) -> List[List[int]]:
         """Captions (token-id lists) of the oldest outstanding batch; blocks until it is decoded."""
@@ -268,8 +297,8 @@ class CaptionPipeline:
         toks, lens = self.host_tok[gslot], self.host_len[gslot]
         return [toks[b, :int(lens[b])].tolist() for b in range(gpos * self.B, (gpos + 1) * self.B)]
 
-    def __call__(self, images: torch.Tensor) -> List[List[int]]:
-        self.submit(images)
+    def __call__(self, images: torch.Tensor, enc_num_pads: Optional[Sequence[int]] = None) -> List[List[int]]:
+        self.submit(images, enc_num_pads)
         while self.outstanding() > 1:
             self.collect()
         return self.collect()
@@ -304,6 +333,37 @@ def gather_captions(tokens: torch.Tensor, lengths: torch.Tensor, n_items: int, g
     allp = torch.cat(parts, 0).cpu()
     T = tokens.shape[1]
     return [allp[i, :int(allp[i, T])].tolist() for i in range(n_items)]
+
+
+def run_shard(pipe: CaptionPipeline, n_local: int, fetch, pad_idx: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """This rank's shard through the software pipeline: items [0, n_local) in sub-batches of pipe.B (the
+    ragged tail padded with repeats of its last item and trimmed), batches submitted as long as the result
+    ring has room, results collected in order on the device.
+      fetch(lo, hi) → inputs of local items [lo, hi) (device tensor)
+    → (tokens int32 [n_local, T] padded with pad_idx, lengths int32 [n_local]) — the operands of gather_captions."""
+    B, T = pipe.B, pipe.T
+    toks = torch.full((n_local, T), pad_idx, dtype=torch.int32, device=pipe.device)
+    lens = torch.zeros(n_local, dtype=torch.int32, device=pipe.device)
+    pending: List[Tuple[int, int]] = []
+
+    def drain_one():
+        lo, n = pending.pop(0)
+        t, l = pipe.collect_device()
+        toks[lo:lo + n] = t[:n]
+        lens[lo:lo + n] = l[:n]
+
+    for lo in range(0, n_local, B):
+        hi = min(lo + B, n_local)
+        x, n = fetch(lo, hi), hi - lo
+        if n < B:
+            x = torch.cat([x, x[-1:].expand(B - n, *x.shape[1:])], 0)
+        while pipe.full():
+            drain_one()
+        pipe.submit(x.contiguous())
+        pending.append((lo, n))
+    while pending:
+        drain_one()
+    return toks, lens
 
 
 def caption_sharded(caption_batch, n_items: int, fetch, batch: int, T: int, eos_idx: int, device,

@@ -227,3 +227,28 @@ def test_oracle_long_beam5_search_matches_reference(variant):
     pred, lp = R.beam_search(sd, g, W.synth_images(3, g), [0] * 3, 3, 2, 5, 2, g.max_seq_len)
     assert pred == unpad(store[f"{variant}.beam5_T{g.max_seq_len}.tokens"])
     np.testing.assert_allclose(lp.numpy(), store[f"{variant}.beam5_T{g.max_seq_len}.logprobs"], atol=2e-5)
+
+
+# ----------------------------------------------------------------------------------- F1: caption cleaner
+def test_caption_cleaner_matches_reference_strings():
+    """utils/language_utils.py:4-72 restated in language_utils.py: every helper reproduces the strings the
+    reference's functions returned for the recorded raw captions (oracle/make_golden_text.py)."""
+    from on_device_image_captioning_amd import language_utils as L
+    g = json.load(open(os.path.join(GOLDEN, "text_cleaner.json")))
+    raw = g["raw"]
+    lo = L.lowercase_and_clean_trailing_spaces(raw)
+    assert lo == g["lowercase_and_clean_trailing_spaces"]
+    sp = L.add_space_between_non_alphanumeric_symbols(lo)
+    assert sp == g["add_space_between_non_alphanumeric_symbols"]
+    rp = L.remove_punctuations(sp)
+    assert rp == g["remove_punctuations"]
+    tk = L.tokenize(rp)
+    assert tk == g["tokenize"]
+    assert L.remove_punctuations(raw) == g["remove_punctuations_direct"]
+    assert L.tokenize(raw) == g["tokenize_direct"]
+    assert L.compute_num_pads(g["compute_num_pads_in"]) == g["compute_num_pads"]
+    ids = L.convert_allsentences_word2idx(tk, g["word2idx"])
+    assert ids == g["convert_allsentences_word2idx"]
+    i2w = sorted(g["word2idx"], key=g["word2idx"].get)
+    assert L.convert_allsentences_idx2word(ids, i2w) == g["convert_allsentences_idx2word"]
+    assert L.clean_captions(raw) == [" ".join(t) for t in g["tokenize"]]

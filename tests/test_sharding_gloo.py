@@ -74,3 +74,65 @@ def test_shard_indices_properties():
             assert all(s[2] == spans[0][2] for s in spans)
             assert [i for lo, hi, _ in spans for i in range(lo, hi)] == list(range(n))
             assert all(hi - lo <= per for lo, hi, per in spans)
+
+
+class _FakePipe:
+    """Host-visible contract of CaptionPipeline that run_shard relies on (B, T, device, full / submit /
+    collect_device in submission order, a bounded result ring)."""
+
+    def __init__(self, batch, ring=3):
+        self.B, self.T, self.device, self.ring, self.q = batch, T, torch.device("cpu"), ring, []
+        self.max_outstanding = 0
+
+    def full(self):
+        return len(self.q) >= self.ring
+
+    def submit(self, imgs):
+        assert imgs.shape[0] == self.B and not self.full()
+        self.q.append(imgs.clone())
+        self.max_outstanding = max(self.max_outstanding, len(self.q))
+
+    def collect_device(self):
+        imgs = self.q.pop(0)
+        toks = torch.full((self.B, T), EOS, dtype=torch.int32)
+        lens = torch.zeros(self.B, dtype=torch.int32)
+        for i in range(self.B):
+            c = fake_caption(int(imgs[i, 0, 0, 0]))
+            toks[i, :len(c)] = torch.tensor(c, dtype=torch.int32)
+            lens[i] = len(c)
+        return toks, lens
+
+
+def _worker_run_shard(rank, world, port, n_items, batch, out_dir):
+    sys.path.insert(0, ROOT)
+    from on_device_image_captioning_amd.pipeline import gather_captions, run_shard, shard_indices
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi, per = shard_indices(n_items, rank, world)
+    images = torch.arange(n_items, dtype=torch.float32).view(n_items, 1, 1, 1).expand(n_items, 3, 2, 2).contiguous()
+    pipe = _FakePipe(batch)
+    toks, lens = run_shard(pipe, hi - lo, lambda a, b: images[lo + a:lo + b], EOS)
+    pt = torch.full((per, T), EOS, dtype=torch.int32)
+    pl = torch.zeros(per, dtype=torch.int32)
+    pt[:hi - lo], pl[:hi - lo] = toks, lens
+    caps = gather_captions(pt, pl, n_items)
+    torch.save({"caps": caps, "max_outstanding": pipe.max_outstanding}, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items,batch", [(23, 4), (9, 16)])
+def test_run_shard_pipelined_two_ranks(tmp_path, n_items, batch):
+    """bench.py's coco5k step: the shard goes through the pipeline with several batches outstanding, ragged
+    tail padded, rows land at their local index, one all_gather restores the global order."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_run_shard, args=(world, port, n_items, batch, str(tmp_path)), nprocs=world, join=True)
+    want = [fake_caption(i) for i in range(n_items)]
+    for r in range(world):
+        d = torch.load(os.path.join(str(tmp_path), f"s{r}.pt"))
+        assert d["caps"] == want, f"rank {r}"
+        if n_items / world / batch > 3:
+            assert d["max_outstanding"] == 3                # the ring was kept full

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r01_pmc_traffic.json from two rocprofv3 counter_collection.csv files (FETCH_SIZE pass, WRITE_SIZE
+"""profiles/r02_pmc_traffic.json from two rocprofv3 counter_collection.csv files (FETCH_SIZE pass, WRITE_SIZE
 pass): HBM bytes per launch of each kernel family bench.py reports = (2·FETCH_SIZE + WRITE_SIZE)·1024 (gfx950
 correction of MI355X_MICROARCH.md §HBM).    python tools/pmc_traffic_json.py fetch.csv write.csv out.json "<cmd>" """
 import csv
@@ -39,6 +39,11 @@ for fam in fetch:
                 "launches_sampled": nf[fam],
                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md "
                           "§HBM; " + (sys.argv[4] if len(sys.argv) > 4 else "")}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_source_hash: which HIP sources these counters describe)
+out["_meta"] = {"kernel_source_hash": bench.kernel_source_hash(), "command": sys.argv[4] if len(sys.argv) > 4 else ""}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in out.items():
-    print(k, v["hbm_bytes_per_launch"], v["launches_sampled"])
+    if k != "_meta":
+        print(k, v["hbm_bytes_per_launch"], v["launches_sampled"])

@@ -58,7 +58,7 @@ for s in range(4):
     graphs.append(gr); names.append(f"swin stage {s}")
 gr = torch.cuda.CUDAGraph()
 with torch.cuda.graph(gr, stream=s_enc):
-    _, mem16 = cap.encode(feats, pipe.enc_len, want_bf16_mem=True)
+    _, mem16 = cap.encode(feats, pipe.enc_lens[0], want_bf16_mem=True)
     cap.project_kv(mem16, out=pipe.kv_stage)
 graphs.append(gr); names.append("expansion encoder + K/V")
 torch.cuda.synchronize()
