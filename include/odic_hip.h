@@ -40,7 +40,7 @@ extern "C" {
 #define ODIC_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ODIC_ABI_VERSION 6
+#define ODIC_ABI_VERSION 7
 int odic_abi_version(void);
 
 /* Human-readable build string ("gfx950 hipcc ..."), static storage. */
@@ -69,7 +69,8 @@ typedef struct odic_gemm_args {
   int32_t bias_axis;  /* 0: bias[n]   1: bias[m] */
   int32_t in_dtype;   /* dtype of A and W */
   int32_t out_dtype;  /* dtype of out */
-  int32_t tile_cfg;   /* bf16 only: tile configuration 0..11 (see csrc/gemm_bf16.hip), -1 = built-in choice */
+  int32_t tile_cfg;   /* bf16 only: tile configuration (see csrc/gemm_bf16.hip): 0..12 one block per tile,
+                       * 16 + c = config c as a persistent launch (needs `workspace`, batch == 1); -1 = built-in choice */
   /* Optional LayerNorm of the A operand, folded (fp32 skinny-M path only: M <= 192, K % 16 == 0,
    * bias_axis 0).  The caller prepares  W' = W·diag(gamma),  ln_colsum[n] = Σ_k W'[n][k]  and
    * bias' = bias + W·beta, passes W' / bias' as W / bias, and the kernel computes
@@ -79,12 +80,12 @@ typedef struct odic_gemm_args {
    * Replaces the separate norm_1/2/3 + dec_reduce_norm launches of the decoder step
    * (layers.py:225,228,232; End_ExpansionNet_v2.py:135).  NULL = plain GEMM. */
   const float* ln_colsum; float ln_eps;
+  /* bf16 persistent tile configurations only: 16 int32 of device memory, all zero when the launch starts;
+   * the kernel leaves them zero again, so ONE buffer serves every launch of a stream (launches of different
+   * streams that may overlap need their own).  NULL otherwise. */
+  int32_t* workspace;
 } odic_gemm_args;
 int odic_gemm(const odic_gemm_args* args, void* stream);
-
-/* Test hook: force the bf16 tile configuration for every call that passes tile_cfg = -1
- * (-1 restores the built-in choice).  Process-global; not for production use. */
-void odic_gemm_bf16_force_config(int cfg);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps inside sqrt, biased variance — torch.nn.LayerNorm).

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libodic_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _ERR = {-1: "ODIC_EINVAL (bad shape / alignment / enum)", -2: "ODIC_ENULL (required pointer is NULL)",
         -3: "ODIC_EUNSUPPORTED"}
@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
                 ("strideR", C.c_int64), ("strideC", C.c_int64),
                 ("alpha", C.c_float), ("act", C.c_int32), ("bias_axis", C.c_int32),
                 ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile_cfg", C.c_int32),
-                ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float)]
+                ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("workspace", C.c_void_p)]
 
 
 class BeamState(C.Structure):
@@ -45,7 +45,6 @@ _SIGNATURES = {
     "odic_abi_version": (C.c_int, []),
     "odic_build_info": (C.c_char_p, []),
     "odic_gemm": (C.c_int, [C.POINTER(GemmArgs), _P]),
-    "odic_gemm_bf16_force_config": (None, [C.c_int]),
     "odic_layernorm": (C.c_int, [_P, _I64, _P, _P, _P, _I32, _I32, _F, _I32, _P]),
     "odic_cast_f32_to_bf16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P]),
     "odic_patch_merge_layernorm": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _F, _I32, _P]),

@@ -25,6 +25,8 @@
 //     while its A panels stream through once (PMC: L2 hit rate 70 % → see profiles/).
 //   * rows/cols beyond M/N are clamped on load (valid memory, discarded on store).
 #include "odic_common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -37,6 +39,7 @@ struct Params {
   float alpha; int act; int bias_axis;
   int tiles_m, tiles_n;
   int pm, pn;          // XCD partition of the tile grid, pm * pn == 8
+  int* ws;             // persistent kernels: 8 per-partition tile counters + 1 exit counter (all zero at launch)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -220,6 +223,253 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
           }
         }
       }
+    }
+  }
+}
+
+
+
+// One K-tile of LDS-DMA for the persistent kernel: `buffer_load ... lds` with the tile origins in scalar resource
+// descriptors, per-lane 32-bit offsets and the K advance as the scalar offset.  (A free function: a local of the
+// buffer-resource type inside a lambda of a __global__ template suppresses the kernel's host stub on ROCm 7.2.)
+template <int A_INSTR, int W_INSTR, int NW>
+__device__ __forceinline__ void persist_stage(char* la, int a_bytes, const bf16_raw* a_base, const bf16_raw* w_base,
+                                              const int* voff_a, const int* voff_w, int wave, int koff) {
+  char* lw = la + a_bytes;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(la + (i * NW + wave) * 1024), 16, voff_a[i], koff, 0, 0);
+#pragma unroll
+  for (int i = 0; i < W_INSTR; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(lw + (i * NW + wave) * 1024), 16, voff_w[i], koff, 0, 0);
+}
+
+// =================================================================================================
+// Persistent, dynamically scheduled form of the generic kernel (tile_cfg 16 + c runs tile config c this way).
+//
+// Why: a Swin-L product is 100..1700 tiles on 256 CUs x (1..3 resident blocks), i.e. 1-3 "rounds" with a ragged
+// last one, and beside the decoder-step kernels of the other HIP streams some CUs are slower than others — with
+// one block per tile the launch ends with its slowest CU (the straggler effect).  Here a launch is
+// only as many blocks as fit the chip; every block pulls tiles from per-XCD-partition atomic counters until the
+// product is done, so a slowed CU simply takes fewer tiles, and a partition that runs dry steals from the next.
+//   * tile order inside a partition is unchanged (N-fastest inside the XCD's rectangle → its W sub-panel stays in
+//     the XCD's L2 and an A panel is consumed by all its column tiles while resident);
+//   * the NEXT tile's ticket is drawn (one returning atomic by one lane) right after the current tile's first
+//     K-tiles have been requested and is only looked at after the K-loop, so its latency costs nothing;
+//     (vmcnt retires in order and counts stores, so a tile's first K-tile cannot be consumed before the previous
+//     epilogue's stores are acknowledged: requesting it ahead of the epilogue buys nothing inside one wave —
+//     prologue and store tail overlap across the 2-3 resident blocks of a CU instead);
+//   * LDS-DMA as `buffer_load ... lds`: the tile's base sits in a scalar resource descriptor, the per-lane part
+//     is a 32-bit offset computed once per tile and the K advance is the scalar offset — no 64-bit address
+//     arithmetic per issue.
+// Workspace protocol: ws[0..7] tile counters, ws[8] exit counter; the caller hands zeros, the last block to
+// leave zeroes them again (kernel boundary = release), so one workspace serves all launches of a stream.
+// Blocks never wait for each other: no residency requirement, nothing can hang.
+// =================================================================================================
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK, typename OutT>
+__global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_persist_kernel(Params p) {
+  constexpr int NW = NWM * NWN;
+  constexpr int ROWB = BK * 2;
+  constexpr int RPI = 1024 / ROWB;
+  constexpr int CPR = ROWB / 16;
+  constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
+  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
+  constexpr int A_INSTR = BM / RPI / NW, W_INSTR = BN / RPI / NW;
+  static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "tile rows must split evenly over the waves");
+  constexpr int G = A_INSTR + W_INSTR;
+  static_assert(NI % 2 == 0, "the epilogue pairs MFMA column tiles");
+  constexpr int D = NSTAGE - 1;
+  extern __shared__ __attribute__((aligned(16))) char lds[];          // stages | int slot[2] (next-tile mailbox)
+  typedef __attribute__((address_space(3))) int lds_int;
+  lds_int* slot = (lds_int*)(lds + NSTAGE * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  ODIC_ENCODE_PRIO();
+
+  // ---- tile source.  Partition `part` of the tile grid (the XCD rectangles of the one-block-per-tile kernel)
+  //      has its own counter; a block starts on partition blockIdx % 8 and moves on when that one runs dry.
+  const int xcd = blockIdx.x & 7;
+  int dry = 0;                                                        // partitions this block has seen exhausted
+  int p_r0 = 0, p_c0 = 0, p_w = 1, p_size = 0;                        // rectangle of the current partition
+  auto load_part = [&]() {
+    const int part = (xcd + dry) & 7;
+    const int xm = part / p.pn, xn = part - xm * p.pn;
+    const int r1 = (xm + 1) * p.tiles_m / p.pm, c1 = (xn + 1) * p.tiles_n / p.pn;
+    p_r0 = xm * p.tiles_m / p.pm; p_c0 = xn * p.tiles_n / p.pn;
+    p_w = c1 - p_c0; p_size = (r1 - p_r0) * p_w;
+  };
+  auto decode = [&](int idx) -> int {
+    const int lr = idx / p_w;
+    return ((p_r0 + lr) << 16) | (p_c0 + idx - lr * p_w);
+  };
+  auto draw = [&]() -> int {                                          // returning atomic, result not waited for here
+    return __hip_atomic_fetch_add(p.ws + ((xcd + dry) & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto resolve = [&](int idx) -> int {                                // ticket → tile, stealing when the partition is dry
+    while (idx >= p_size) {
+      if (++dry >= 8) return -1;
+      load_part();
+      if (p_size > 0) idx = draw(); else idx = 0x7fffffff;
+    }
+    return decode(idx);
+  };
+  load_part();
+
+  const int srow = lane / CPR;
+  const int schunk = swz<BK>(lane % CPR, srow);
+  const int frow = lane & 15, fq = lane >> 4;
+  const int nk = p.K / BK;
+  const bf16_raw* A = p.A;
+  const bf16_raw* W = p.W;
+
+  int m0 = 0, n0 = 0;
+  const bf16_raw* a_base = A;                                          // tile origins (wave-uniform)
+  const bf16_raw* w_base = W;
+  int voff_a[A_INSTR], voff_w[W_INSTR];
+  auto setup = [&](int tile) {                                         // tile is wave-uniform (SGPR)
+    m0 = (tile >> 16) * BM; n0 = (tile & 0xffff) * BN;
+    a_base = A + (long)m0 * p.lda;
+    w_base = W + (long)n0 * p.ldw;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+      const int row = (i * NW + wave) * RPI + srow;
+      voff_a[i] = (min(m0 + row, p.M - 1) - m0) * (int)p.lda * 2 + schunk * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < W_INSTR; ++i) {
+      const int row = (i * NW + wave) * RPI + srow;
+      voff_w[i] = (min(n0 + wperm(row), p.N - 1) - n0) * (int)p.ldw * 2 + schunk * 16;
+    }
+  };
+  auto stage = [&](int buf, int kt) {
+    persist_stage<A_INSTR, W_INSTR, NW>(lds + buf * STAGE, A_BYTES, a_base, w_base, voff_a, voff_w, wave, kt * ROWB);
+  };
+
+  // ---- first tile
+  if (tid == 0) slot[0] = resolve(draw());
+  __syncthreads();
+  int tile = __builtin_amdgcn_readfirstlane(slot[0]);
+  const float* bias = p.bias;
+  const float* resid = p.residual;
+  OutT* out = (OutT*)p.out;
+  const bool ld_ok = ((p.ldc & 7) == 0) && (!resid || (p.ldr & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+
+  for (int it = 0; tile >= 0; ++it) {
+    setup(tile);
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+      if (t < nk) stage(t, t);
+    // ticket for the NEXT tile: issued now, looked at after the K-loop (its latency hides behind the whole tile;
+    // it is younger than this tile's first DMA groups, so the counted waits below at most over-wait by one)
+    int ticket = 0;
+    if (tid == 0) ticket = draw();
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+      // (the previous tile's epilogue stores are OLDER than this tile's DMA: a counted wait covers them too)
+      const int ahead = min(D - 1, nk - 1 - kt);
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + D < nk) stage((kt + D) % NSTAGE, kt + D);
+
+      const int cur = kt % NSTAGE;
+      const char* la = lds + cur * STAGE + (wm * MI * 16 + frow) * ROWB;
+      const char* lw = lds + cur * STAGE + A_BYTES + (wn * NI * 16 + frow) * ROWB;
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        bf16x8_t af[MI], wf[NI];
+        const int chunk = swz<BK>(kk * 4 + fq, frow) << 4;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[mi] = *(const bf16x8_t*)(la + mi * 16 * ROWB + chunk);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const bf16x8_t*)(lw + ni * 16 * ROWB + chunk);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    // next tile: resolve the ticket (steals only at the very end of a launch), hand it to the other waves.
+    // slot[] alternates, so a fast wave 0 cannot overwrite a value a slow wave has not read yet.
+    if (tid == 0) slot[(it + 1) & 1] = resolve(ticket);
+
+    // ---- epilogue (lane → 8 adjacent output columns, as in the generic kernel)
+#pragma unroll
+    for (int nq = 0; nq < NI / 2; ++nq) {
+      const int col = n0 + wn * NI * 16 + nq * 32 + fq * 8;
+      if (col >= p.N) continue;
+      float bc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bc[e] = (bias && !p.bias_axis && col + e < p.N) ? bias[col + e] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = m0 + (wm * MI + mi) * 16 + frow;
+        if (row >= p.M) continue;
+        const float brow = (bias && p.bias_axis) ? bias[row] : 0.f;
+        f32x4_t v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f32x4_t pre = acc[mi][2 * nq + h] * p.alpha + f32x4_t{bc[4 * h], bc[4 * h + 1], bc[4 * h + 2], bc[4 * h + 3]} + brow;
+          if (p.act == ODIC_ACT_GELU) {
+            pre = gelu_poly4(pre);
+          } else if (p.act != ODIC_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pre[e] = apply_act<true>(pre[e], p.act);
+          }
+          v[h] = pre;
+        }
+        if (ld_ok && col + 7 < p.N) {
+          if (resid) {
+            const f32x4_t* rp = (const f32x4_t*)(resid + (long)row * p.ldr + col);
+            v[0] += rp[0]; v[1] += rp[1];
+          }
+          OutT* dst = out + (long)row * p.ldc + col;
+          if constexpr (sizeof(OutT) == 4) {
+            ((f32x4_t*)dst)[0] = v[0]; ((f32x4_t*)dst)[1] = v[1];
+          } else {
+            bf16x8_t pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pk[e] = (short)f32_to_bf16(v[0][e]); pk[4 + e] = (short)f32_to_bf16(v[1][e]); }
+            *(bf16x8_t*)dst = pk;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (col + e < p.N) {
+              float x = v[e >> 2][e & 3];
+              if (resid) x += resid[(long)row * p.ldr + col + e];
+              store_from_f32<OutT>(out + (long)row * p.ldc + col + e, x);
+            }
+          }
+        }
+      }
+    }
+    // every wave has finished reading this tile's LDS stages (its last ds_reads fed the MFMAs above) and wave
+    // 0's mailbox write has landed: one barrier, then the stages may be refilled.  (A raw barrier: __syncthreads()
+    // would also wait for the acknowledgement of the epilogue's stores.)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    tile = __builtin_amdgcn_readfirstlane(slot[(it + 1) & 1]);
+  }
+  // ---- leave: the last block re-arms the workspace for the next launch on this stream
+  if (tid == 0) {
+    const int prev = __hip_atomic_fetch_add(p.ws + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(p.ws + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -492,6 +742,54 @@ int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
   return odic_launch_status();
 }
 
+
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK = 64>
+int launch_persist(Params& p, int out_dtype, int batch, hipStream_t stream) {
+  constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
+  constexpr int SHMEM = NSTAGE * (BM + BN) * BK * 2 + 16;
+  if (p.K % BK != 0 || batch != 1 || !p.ws) return ODIC_EINVAL;
+  if ((long)(BM - 1) * p.lda * 2 + 2L * p.K >= 0x7fffffffL || (long)(BN - 1) * p.ldw * 2 + 2L * p.K >= 0x7fffffffL)
+    return ODIC_EINVAL;                        // 32-bit byte offsets inside a tile's buffer resource
+  p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+  if (p.tiles_m > 65535 || p.tiles_n > 65535) return ODIC_EINVAL;
+  int pn = 1;
+  while (pn < 8 && pn * 2 <= p.tiles_n && (double)p.N / pn * p.K * 2.0 > 2.5 * 1024 * 1024) pn *= 2;
+  int pm = 8 / pn;
+  while (pm > p.tiles_m && pm > 1) { pm /= 2; pn *= 2; }
+  if (pn > p.tiles_n) { pn = 1; pm = 8; while (pm > p.tiles_m && pm > 1) pm /= 2; pn = 8 / pm; }
+  p.pm = pm; p.pn = pn;
+  auto kb = gemm_bf16_nt_persist_kernel<NWM, NWN, MI, NI, NSTAGE, BK, bf16_raw>;
+  auto kf = gemm_bf16_nt_persist_kernel<NWM, NWN, MI, NI, NSTAGE, BK, float>;
+  static int per_cu = 0;                       // resident blocks per CU of this instantiation (code-object property)
+  if (!per_cu) {
+    if (SHMEM > 64 * 1024) {
+      (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+      (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+    }
+    // resident blocks per CU from the code object's own numbers (LDS, registers, wave slots); blocks never wait
+    // for each other, so an estimate that is one too high or too low only costs a little speed
+    int nb = (160 * 1024) / SHMEM;
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, (const void*)kb) == hipSuccess && fa.numRegs > 0) {
+      const int alloc = (fa.numRegs + 7) / 8 * 8;
+      const int waves_per_simd = 512 / alloc < 8 ? 512 / alloc : 8;
+      const int by_regs = waves_per_simd * 4 / (NWM * NWN);
+      if (by_regs < nb) nb = by_regs;
+    }
+    if (32 / (NWM * NWN) < nb) nb = 32 / (NWM * NWN);
+    per_cu = nb < 1 ? 1 : nb;
+    if (getenv("ODIC_GEMM_DEBUG"))
+      fprintf(stderr, "[odic_gemm] persistent %dx%dx%d stages %d: %d B LDS, %d regs -> %d blocks/CU\n", BM, BN, BK, NSTAGE,
+              SHMEM, fa.numRegs, per_cu);
+  }
+  const long tiles = (long)p.tiles_m * p.tiles_n;
+  const long slots = 256L * per_cu;
+  dim3 grid((unsigned)(tiles < slots ? tiles : slots)), block(64 * NWM * NWN);
+  if (out_dtype == ODIC_BF16) hipLaunchKernelGGL(kb, grid, block, SHMEM, stream, p);
+  else hipLaunchKernelGGL(kf, grid, block, SHMEM, stream, p);
+  return odic_launch_status();
+}
+
 int launch_256sq(Params& p, int out_dtype, int batch, hipStream_t stream) {
   constexpr int SHMEM = 128 * 1024;
   if (p.K % 128 != 0) return ODIC_EINVAL;
@@ -524,11 +822,7 @@ int launch_256sq(Params& p, int out_dtype, int batch, hipStream_t stream) {
   return odic_launch_status();
 }
 
-int g_force_cfg = -1;      // test / tuning hook: odic_gemm_bf16_force_config()
-
 }  // namespace
-
-extern "C" void odic_gemm_bf16_force_config(int cfg) { g_force_cfg = cfg; }
 
 int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
   if (a->ln_colsum) return ODIC_EUNSUPPORTED;
@@ -542,11 +836,12 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
   p.strideA = a->strideA; p.strideW = a->strideW; p.strideBias = a->strideBias;
   p.strideR = a->strideR; p.strideC = a->strideC;
   p.alpha = a->alpha; p.act = a->act; p.bias_axis = a->bias_axis;
+  p.ws = a->workspace;
   // Tile choice = fewest "rounds x per-tile cost": a launch runs in ceil(tiles / resident slots)
   // rounds (256 CUs x 3 / 2 / 1 blocks for the 128x64 / 128x128 / 256x256 tiles, set by their LDS
   // footprints); relative per-tile costs 1 : 1.38 : 2.6 were measured on MI355X over the Swin-L
   // shapes (tools/gemm_tune.py; profiles/r01_gemm_tile_sweep.txt).
-  int cfg = a->tile_cfg >= 0 ? a->tile_cfg : g_force_cfg;
+  int cfg = a->tile_cfg;
   if (cfg < 0) {
     auto rounds = [&](int bm, int bn, int slots) {
       const long t = (long)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn) * a->batch;
@@ -570,6 +865,18 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     case 10: return launch_cfg<4, 2, 4, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32, 3 stages (72 KiB)
     case 11: return launch_cfg<2, 4, 8, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32, 3 stages (96 KiB)
     case 12: return launch_256sq(p, a->out_dtype, a->batch, stream);                 // 256 x 256 x 64, 4 phases per K-tile (128 KiB)
+    // 16 + c: tile config c as a persistent, dynamically scheduled launch (needs args->workspace, batch == 1)
+    case 16: return launch_persist<2, 2, 4, 2, 2>(p, a->out_dtype, a->batch, stream);
+    case 17: return launch_persist<2, 2, 4, 4, 2>(p, a->out_dtype, a->batch, stream);
+    case 18: return launch_persist<2, 4, 8, 4, 2>(p, a->out_dtype, a->batch, stream);
+    case 19: return launch_persist<2, 2, 4, 2, 3>(p, a->out_dtype, a->batch, stream);
+    case 20: return launch_persist<2, 2, 4, 4, 3>(p, a->out_dtype, a->batch, stream);
+    case 21: return launch_persist<4, 2, 4, 4, 3>(p, a->out_dtype, a->batch, stream);
+    case 23: return launch_persist<4, 2, 4, 4, 2, 32>(p, a->out_dtype, a->batch, stream);
+    case 24: return launch_persist<2, 2, 4, 4, 2, 32>(p, a->out_dtype, a->batch, stream);
+    case 25: return launch_persist<2, 4, 8, 4, 2, 32>(p, a->out_dtype, a->batch, stream);
+    case 26: return launch_persist<4, 2, 4, 4, 3, 32>(p, a->out_dtype, a->batch, stream);
+    case 27: return launch_persist<2, 4, 8, 4, 3, 32>(p, a->out_dtype, a->batch, stream);
     default: return ODIC_EINVAL;
   }
 }

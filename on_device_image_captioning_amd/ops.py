@@ -97,7 +97,19 @@ def dtype_code(dt: torch.dtype) -> int:
 # fastest; later calls (including the captured ones) reuse the choice.
 _TILE_CHOICE: dict = {}
 _TUNING = False
-_TILE_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_TILE_CANDIDATES", "0,1,7,10").split(","))
+_TILE_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_TILE_CANDIDATES", "0,1,7,10,16,17,23,26").split(","))
+
+# persistent tile configurations (16 + c) draw tiles from atomic counters in a 16-int workspace that is zero at
+# launch and left zero by the kernel: launches of one stream are ordered, so one buffer per stream suffices
+_GEMM_WS: dict = {}
+
+
+def _gemm_workspace(device: torch.device) -> torch.Tensor:
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _GEMM_WS.get(key)
+    if ws is None:
+        ws = _GEMM_WS[key] = torch.zeros(16, dtype=torch.int32, device=device)
+    return ws
 
 
 class autotune:
@@ -145,7 +157,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
          M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None,
          lda: Optional[int] = None, ldw: Optional[int] = None, ldr: Optional[int] = None,
          ldc: Optional[int] = None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideBias: int = 0,
-         strideR: int = 0, strideC: int = 0, ln_fold: Optional[tuple] = None) -> torch.Tensor:
+         strideR: int = 0, strideC: int = 0, ln_fold: Optional[tuple] = None, tile_cfg: int = -1) -> torch.Tensor:
     """out = act(alpha·A·Wᵀ + bias) + residual.  With no explicit dims, A is [..., K] (flattened to
     [M,K]) and W is [N,K], both contiguous.  Explicit dims / leading dimensions / batch strides allow
     strided sub-matrices (elements).  ln_fold = (colsum, eps): W and bias come from fold_layernorm() and
@@ -177,11 +189,13 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
         raise RuntimeError("residual must be fp32")
     a = _hip.GemmArgs(_p(A), _p(W), _p(bias), _p(residual), _p(out), M, N, K, lda, ldw, ldr or 0, ldc, batch,
                       strideA, strideW, strideBias, strideR, strideC, alpha, act, bias_axis,
-                      dtype_code(A.dtype), dtype_code(out.dtype), -1,
-                      _p(ln_fold[0]) if ln_fold else None, float(ln_fold[1]) if ln_fold else 0.0)
+                      dtype_code(A.dtype), dtype_code(out.dtype), tile_cfg,
+                      _p(ln_fold[0]) if ln_fold else None, float(ln_fold[1]) if ln_fold else 0.0, None)
     if A.dtype == torch.bfloat16:
+        if batch == 1:
+            a.workspace = _gemm_workspace(A.device).data_ptr()
         key = (M, N, K, batch, out.dtype, act, residual is not None)
-        cfg = _TILE_CHOICE.get(key)
+        cfg = _TILE_CHOICE.get(key) if tile_cfg < 0 else tile_cfg
         if cfg is None and _TUNING and _PROFILE is None and ldc == N and batch == 1 \
                 and not torch.cuda.is_current_stream_capturing():
             cfg = _tune_gemm(a, key, out)

@@ -357,41 +357,53 @@ def test_dynexp_step_matches_full_recompute(ops):
 def test_gemm_bf16_256sq_phase_pipeline(ops):
     """Config 12 (256x256 tile, four phases per K-tile, counted LDS-DMA waits): ragged M/N, 2..24 K-tiles,
     every epilogue feature, and run-to-run identical results (a pipeline race shows up as flicker)."""
-    from on_device_image_captioning_amd import _hip
-    lib = _hip.load()
-    try:
-        lib.odic_gemm_bf16_force_config(12)
-        for (M, N, K) in ((300, 328, 128), (517, 260, 384), (1024, 768, 768), (2304, 1536, 1536), (700, 3072, 256)):
-            A, Wt = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=0.05).bfloat16()
-            b, r = rnd(N, seed=3), rnd(M, N, seed=4)
-            want = torch.relu(0.5 * (A.double() @ Wt.double().T) + b.double()) + r.double()
-            dA, dW, db, dr = dev(A), dev(Wt), dev(b), dev(r)
-            got = ops.gemm(dA, dW, db, dr, act=2, alpha=0.5, out_dtype=torch.float32)
-            assert_close(got, want, 2e-4, f"cfg12 {M}x{N}x{K}")
-            for _ in range(20):
-                again = ops.gemm(dA, dW, db, dr, act=2, alpha=0.5, out_dtype=torch.float32)
-                assert torch.equal(again, got), f"cfg12 {M}x{N}x{K}: results differ between launches"
-            got16 = ops.gemm(dA, dW, db, act=1, out_dtype=torch.bfloat16)
-            assert_close(got16, torch.nn.functional.gelu(A.double() @ Wt.double().T + b.double()), 6e-3, "cfg12 gelu→bf16")
-        with pytest.raises(RuntimeError):                 # K-tiles are consumed in pairs
-            ops.gemm(dev(rnd(256, 192, seed=1)).bfloat16(), dev(rnd(256, 192, seed=2)).bfloat16())
-    finally:
-        lib.odic_gemm_bf16_force_config(-1)
+    for (M, N, K) in ((300, 328, 128), (517, 260, 384), (1024, 768, 768), (2304, 1536, 1536), (700, 3072, 256)):
+        A, Wt = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=0.05).bfloat16()
+        b, r = rnd(N, seed=3), rnd(M, N, seed=4)
+        want = torch.relu(0.5 * (A.double() @ Wt.double().T) + b.double()) + r.double()
+        dA, dW, db, dr = dev(A), dev(Wt), dev(b), dev(r)
+        got = ops.gemm(dA, dW, db, dr, act=2, alpha=0.5, out_dtype=torch.float32, tile_cfg=12)
+        assert_close(got, want, 2e-4, f"cfg12 {M}x{N}x{K}")
+        for _ in range(20):
+            again = ops.gemm(dA, dW, db, dr, act=2, alpha=0.5, out_dtype=torch.float32, tile_cfg=12)
+            assert torch.equal(again, got), f"cfg12 {M}x{N}x{K}: results differ between launches"
+        got16 = ops.gemm(dA, dW, db, act=1, out_dtype=torch.bfloat16, tile_cfg=12)
+        assert_close(got16, torch.nn.functional.gelu(A.double() @ Wt.double().T + b.double()), 6e-3, "cfg12 gelu→bf16")
+    with pytest.raises(RuntimeError):                 # K-tiles are consumed in pairs
+        ops.gemm(dev(rnd(256, 192, seed=1)).bfloat16(), dev(rnd(256, 192, seed=2)).bfloat16(), tile_cfg=12)
 
 
-@pytest.mark.parametrize("cfg", list(range(12)))
+PERSISTENT_CFGS = [16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27]
+
+
+@pytest.mark.parametrize("cfg", list(range(12)) + PERSISTENT_CFGS)
 def test_gemm_bf16_every_tile_config(ops, cfg):
-    """Each tile / pipeline-depth / BK instantiation against fp64 on ragged shapes (M, N not multiples
-    of any tile) with every epilogue feature on."""
-    from on_device_image_captioning_amd import _hip
-    lib = _hip.load()
-    try:
-        lib.odic_gemm_bf16_force_config(cfg)
-        for (M, N, K) in ((300, 328, 192), (517, 260, 320)):
-            A, Wt = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=0.05).bfloat16()
-            b, r = rnd(N, seed=3), rnd(M, N, seed=4)
-            want = torch.relu(0.5 * (A.double() @ Wt.double().T) + b.double()) + r.double()
-            got = ops.gemm(dev(A), dev(Wt), dev(b), dev(r), act=2, alpha=0.5, out_dtype=torch.float32)
-            assert_close(got, want, 2e-4, f"cfg{cfg} {M}x{N}x{K}")
-    finally:
-        lib.odic_gemm_bf16_force_config(-1)
+    """Each tile / pipeline-depth / BK instantiation — one block per tile (0..11) and persistent with dynamic tile
+    scheduling (16 + c) — against fp64 on ragged shapes (M, N not multiples of any tile) with every epilogue
+    feature on."""
+    for (M, N, K) in ((300, 328, 192), (517, 260, 320)):
+        A, Wt = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=0.05).bfloat16()
+        b, r = rnd(N, seed=3), rnd(M, N, seed=4)
+        want = torch.relu(0.5 * (A.double() @ Wt.double().T) + b.double()) + r.double()
+        got = ops.gemm(dev(A), dev(Wt), dev(b), dev(r), act=2, alpha=0.5, out_dtype=torch.float32, tile_cfg=cfg)
+        assert_close(got, want, 2e-4, f"cfg{cfg} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("cfg", [16, 17, 23, 26])
+def test_gemm_bf16_persistent_many_tiles_per_block(ops, cfg):
+    """Persistent launches where every block walks MANY tiles (more tiles than resident slots, tile stealing
+    across XCD partitions at the end), all epilogue forms, the workspace re-armed launch after launch, and
+    bit-identical results to the one-block-per-tile kernel of the same tile configuration (same MFMA order)."""
+    for (M, N, K, act, odt) in ((9216, 3072, 768, 1, torch.bfloat16), (36864, 384, 384, 0, torch.float32),
+                                (20000, 1100, 128, 2, torch.float32)):
+        A, Wt = rnd(M, K, seed=5).bfloat16(), rnd(N, K, seed=6, scale=0.05).bfloat16()
+        b = rnd(N, seed=7)
+        r = rnd(M, N, seed=8) if odt == torch.float32 else None
+        dA, dW, db, dr = dev(A), dev(Wt), dev(b), (dev(r) if r is not None else None)
+        base = ops.gemm(dA, dW, db, dr, act=act, out_dtype=odt, tile_cfg=cfg - 16)
+        for _ in range(4):
+            got = ops.gemm(dA, dW, db, dr, act=act, out_dtype=odt, tile_cfg=cfg)
+            assert torch.equal(got, base), f"cfg{cfg} {M}x{N}x{K}"
+        ws = ops._gemm_workspace(dA.device)
+        torch.cuda.synchronize()
+        assert int(ws.abs().sum()) == 0                    # counters left at zero

@@ -17,7 +17,6 @@ A = torch.randn(M, K, device="cuda").bfloat16()
 W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
 bias = torch.randn(N, device="cuda")
 out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-lib.odic_gemm_bf16_force_config(cfg)
 for _ in range(5):
-    ops.gemm(A, W, bias, out=out, act=act)
+    ops.gemm(A, W, bias, out=out, act=act, tile_cfg=cfg)
 torch.cuda.synchronize()
