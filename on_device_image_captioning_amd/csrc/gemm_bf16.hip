@@ -309,11 +309,26 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_persist_kernel(Pa
   auto draw = [&]() -> int {                                          // returning atomic, result not waited for here
     return __hip_atomic_fetch_add(p.ws + ((xcd + dry) & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  auto resolve = [&](int idx) -> int {                                // ticket → tile, stealing when the partition is dry
+  // ticket → tile; run by ALL lanes of wave 0 with the ticket in lane 0.  When the partition is dry, lanes 0..7 read
+  // the eight counters in ONE wave instruction (past the L1) and the partition with the most tiles left is taken;
+  // nothing left anywhere → -1.  (Eight dependent loads by one lane cost more than the tile itself.)
+  auto resolve = [&](int ticket_lane0) -> int {
+    int idx = __builtin_amdgcn_readfirstlane(ticket_lane0);
     while (idx >= p_size) {
-      if (++dry >= 8) return -1;
+      const int i = lane & 7;
+      const int xm = i / p.pn, xn = i - xm * p.pn;
+      const int sz = ((xm + 1) * p.tiles_m / p.pm - xm * p.tiles_m / p.pm) *
+                     ((xn + 1) * p.tiles_n / p.pn - xn * p.tiles_n / p.pn);
+      int key = ((sz - __hip_atomic_load(p.ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) << 3) | i;
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o, 64));      // lanes 0..7 hold the 8 partitions
+      key = __builtin_amdgcn_readfirstlane(key);
+      if ((key >> 3) <= 0) return -1;
+      dry = ((key & 7) - xcd) & 7;
       load_part();
-      if (p_size > 0) idx = draw(); else idx = 0x7fffffff;
+      int t = 0;
+      if (lane == 0) t = draw();
+      idx = __builtin_amdgcn_readfirstlane(t);
     }
     return decode(idx);
   };
@@ -350,7 +365,12 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_persist_kernel(Pa
   };
 
   // ---- first tile
-  if (tid == 0) slot[0] = resolve(draw());
+  if (wave == 0) {
+    int t = 0;
+    if (lane == 0) t = draw();
+    const int first = resolve(t);
+    if (lane == 0) slot[0] = first;
+  }
   __syncthreads();
   int tile = __builtin_amdgcn_readfirstlane(slot[0]);
   const float* bias = p.bias;
@@ -404,7 +424,10 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_persist_kernel(Pa
     }
     // next tile: resolve the ticket (steals only at the very end of a launch), hand it to the other waves.
     // slot[] alternates, so a fast wave 0 cannot overwrite a value a slow wave has not read yet.
-    if (tid == 0) slot[(it + 1) & 1] = resolve(ticket);
+    if (wave == 0) {
+      const int nx = resolve(ticket);
+      if (lane == 0) slot[(it + 1) & 1] = nx;
+    }
 
     // ---- epilogue (lane → 8 adjacent output columns, as in the generic kernel)
 #pragma unroll

@@ -97,7 +97,7 @@ def dtype_code(dt: torch.dtype) -> int:
 # fastest; later calls (including the captured ones) reuse the choice.
 _TILE_CHOICE: dict = {}
 _TUNING = False
-_TILE_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_TILE_CANDIDATES", "0,1,7,10,16,17,23,26").split(","))
+_TILE_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_TILE_CANDIDATES", "0,1,7,10").split(","))
 
 # persistent tile configurations (16 + c) draw tiles from atomic counters in a 16-int workspace that is zero at
 # launch and left zero by the kernel: launches of one stream are ordered, so one buffer per stream suffices
