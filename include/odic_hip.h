@@ -40,7 +40,7 @@ extern "C" {
 #define ODIC_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ODIC_ABI_VERSION 7
+#define ODIC_ABI_VERSION 8
 int odic_abi_version(void);
 
 /* Human-readable build string ("gfx950 hipcc ..."), static storage. */
@@ -227,6 +227,15 @@ int odic_cross_attn_step(const float* q, int64_t ldq, const float* kv, int64_t l
 int odic_logsoftmax_topk(const float* logits, int64_t ldl, float* logp_out, int64_t ldp,
                          float* top_val, int32_t* top_idx, int32_t N, int32_t V, int32_t k,
                          void* stream);
+
+/* The `sample` variants of the search (captioning_model.py:128-131,166-168: exp(log_probs).multinomial(k,
+ * replacement=False); :59-109 ancestral sampling with k = 1): k words drawn WITHOUT replacement from
+ * softmax(logits[n]) on the device (Gumbel-top-k), top_idx int32 [N,k] in draw order, top_val fp32 [N,k] =
+ * their log-probabilities; logp_out as in odic_logsoftmax_topk.  Noise = Philox4x32-10(seed; row, word/4,
+ * *pos): `pos` (device int32 scalar, may be NULL = 0) separates the steps of a captured graph. */
+int odic_logsoftmax_sample(const float* logits, int64_t ldl, float* logp_out, int64_t ldp, float* top_val,
+                           int32_t* top_idx, int32_t N, int32_t V, int32_t k, uint64_t seed,
+                           const int32_t* pos, void* stream);
 
 /* Ensemble step distribution (ensemble_captioning_model.py:66-83): `logits` is a HOST array of M (<= 8)
  * device pointers to fp32 [N, V] logits (row pitch ldl); out[n][v] = log(mean_m softmax(logits_m[n])[v]). */

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libodic_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _ERR = {-1: "ODIC_EINVAL (bad shape / alignment / enum)", -2: "ODIC_ENULL (required pointer is NULL)",
         -3: "ODIC_EUNSUPPORTED"}
@@ -58,6 +58,7 @@ _SIGNATURES = {
     "odic_dynexp_step": (C.c_int, [_P, _I64, _P, _P] + [_P] * 7 + [_P, _P, _P, _P, _I64, _P, _I64, _P] + [_I32] * 4 + [_F, _P]),
     "odic_cross_attn_step": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P, _P, _P, _I64] + [_I32] * 5 + [_P]),
     "odic_logsoftmax_topk": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _P]),
+    "odic_logsoftmax_sample": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, C.c_uint64, _P, _P]),
     "odic_ensemble_logprobs": (C.c_int, [C.POINTER(C.c_void_p), _I32, _I64, _P, _I64, _I32, _I32, _P]),
     "odic_topk_rows": (C.c_int, [_P, _I64, _P, _P, _I32, _I32, _I32, _P]),
     "odic_beam_step": (C.c_int, [_P, _P, C.POINTER(BeamState), _I32, _I32, _I32, _I64, _P]),

@@ -36,6 +36,9 @@ class CaptioningModel(nn.Module):
         self._eng_cache = None
         self.precision = "fp32"
         self.encoder_precision = None       # None = follow `precision`
+        self.sampling_seed = 0              # Philox key of the device-side draws ('sample' / 'sampling' modes)
+        self._sampling_calls = 0
+        self._draw_log = None               # list → every sampled-beam-search draw is appended (tests)
 
     # ------------------------------------------------------------------ engine cache plumbing
     def check_required_attributes(self):
@@ -54,6 +57,11 @@ class CaptioningModel(nn.Module):
             self._eng_cache = None
         return self
 
+    def _next_sampling_seed(self) -> int:
+        """A fresh Philox key per sampling call (so repeated calls differ), reproducible from `sampling_seed`."""
+        self._sampling_calls += 1
+        return (int(self.sampling_seed) * 0x9E3779B97F4A7C15 + self._sampling_calls) & 0xFFFFFFFFFFFFFFFF
+
     def _apply(self, fn, *a, **k):
         self._eng_cache = None
         return super()._apply(fn, *a, **k)
@@ -63,11 +71,24 @@ class CaptioningModel(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def _device(self) -> torch.device:
+        """GPU the HIP engines of this model live on.  A module moved with `.to('cuda:N')` runs there.  A module
+        left on the host — demo.py:68-104 builds the model with rank='cpu', loads the checkpoint and never calls
+        `.to()` — keeps its nn.Parameters on the host and the engines pack their own copy of the weights onto
+        `rank` if that names a GPU, else cuda:0; inputs are moved there, results come back on the input's
+        device.  Arithmetic is HIP in every case: without a GPU this raises (there is no CPU fallback)."""
         dv = next(self.parameters()).device
-        if dv.type != "cuda":
-            raise RuntimeError("the HIP path needs the model on a GPU (model.to('cuda:N')); there is no CPU "
-                               "fallback in this package")
-        return dv
+        if dv.type == "cuda":
+            return dv
+        if not torch.cuda.is_available():
+            raise RuntimeError("the HIP path needs a GPU and none is visible; there is no CPU fallback in this package")
+        r = self.rank
+        if isinstance(r, int) and not isinstance(r, bool):
+            return torch.device("cuda", r)
+        if isinstance(r, torch.device) and r.type == "cuda":
+            return r
+        if isinstance(r, str) and r.startswith("cuda"):
+            return torch.device(r)
+        return torch.device("cuda", 0)
 
     # ------------------------------------------------------------------ to be provided
     def forward_enc(self, enc_input, enc_input_num_pads):
@@ -112,7 +133,8 @@ class CaptioningModel(nn.Module):
                 mode="forward", **kwargs):
         if mode == "forward":
             x = self.forward_enc(enc_x, enc_x_num_pads)
-            return self.forward_dec(x, enc_x_num_pads, dec_x, dec_x_num_pads, apply_log_softmax)
+            y = self.forward_dec(x, enc_x_num_pads, dec_x, dec_x_num_pads, apply_log_softmax)
+            return y.to(enc_x.device) if isinstance(enc_x, torch.Tensor) else y
         assert ("sos_idx" in kwargs.keys() or "eos_idx" in kwargs.keys()), \
             "sos and eos must be provided in case of batch sampling or beam search"
         sos_idx = kwargs.get("sos_idx", -999)
@@ -132,10 +154,11 @@ class CaptioningModel(nn.Module):
     def get_batch_multiple_sampled_prediction(self, enc_input, enc_input_num_pads, num_outputs, sos_idx, eos_idx,
                                               max_seq_len):
         """mode='sampling' (legacy_models/captioning_model.py:59-109): `num_outputs` ancestral samples per
-        image.  Each step runs the incremental decoder, a device-side log-softmax and one
-        torch.multinomial draw per sequence (the draws use torch's device RNG, so individual samples are
-        not reproducible against the reference's CPU generator; what IS checkable — and tested — is that
-        every reported log-prob equals the teacher-forced log-prob of the returned sequence)."""
+        image.  Each step runs the incremental decoder and ONE kernel that normalises the row and draws the
+        next word on the device (odic_logsoftmax_sample, Philox noise keyed by `self.sampling_seed`, the row and
+        the position) — no host round trip, no ATen launch.  The draws cannot be those of the reference's CPU
+        generator; what IS checkable — and tested — is that every reported log-prob equals the teacher-forced
+        log-prob of the returned sequence, and that the draw frequencies follow the distribution."""
         eng = self._captioner_engine()
         dv = eng.device
         mem = self.forward_enc(enc_input, enc_input_num_pads)
@@ -147,19 +170,21 @@ class CaptioningModel(nn.Module):
         st.anc.copy_(torch.arange(N, dtype=torch.int32, device=dv)[:, None].expand(N, max_seq_len + 1))
         st.next_tok.fill_(sos_idx)
         st.row_valid.fill_(1)
-        logp = torch.empty(N, V, dtype=torch.float32, device=dv)
+        draw_val = torch.empty(N, 1, dtype=torch.float32, device=dv)
+        draw_idx = torch.empty(N, 1, dtype=torch.int32, device=dv)
         toks = torch.full((N, max_seq_len + 1), sos_idx, dtype=torch.int64, device=dv)
         lps = torch.zeros(N, max_seq_len + 1, dtype=torch.float32, device=dv)
         where_eos = torch.full((N,), max_seq_len, dtype=torch.int64, device=dv)
         finished = torch.zeros(N, dtype=torch.bool, device=dv)
+        seed = self._next_sampling_seed()
         t = 0
         while t < max_seq_len:
             st.pos.fill_(t)
             eng.step_logits(st)
-            ops.logsoftmax_topk(st.logits, V, logp, V, st.cand_val, st.cand_idx, N, V, 1)
-            nxt = torch.multinomial(torch.exp(logp), 1).squeeze(1)
+            ops.logsoftmax_sample(st.logits, V, None, 0, draw_val, draw_idx, N, V, 1, seed, st.pos)
+            nxt = draw_idx[:, 0].long()
             toks[:, t + 1] = nxt
-            lps[:, t + 1] = logp.gather(1, nxt[:, None]).squeeze(1)
+            lps[:, t + 1] = draw_val[:, 0]
             t += 1
             hit = nxt == eos_idx
             where_eos = torch.minimum(where_eos, torch.where(hit, torch.full_like(where_eos, t), where_eos))
@@ -170,9 +195,12 @@ class CaptioningModel(nn.Module):
         toks_h, eos_h = toks.cpu(), where_eos.cpu()
         res = [[toks_h[i * num_outputs + j, :int(eos_h[i * num_outputs + j]) + 1].tolist()
                 for j in range(num_outputs)] for i in range(bs)]
-        ar = torch.arange(t + 1, device=dv)[None, :]
-        probs = lps[:, :t + 1].masked_fill(ar > where_eos[:, None], 0.0).reshape(bs, num_outputs, -1)
-        return res, probs
+        # the reference stops at the step every sequence has finished (:96-97) and pads to the longest one: the
+        # host only looks every _DONE_POLL steps, so trim the columns the extra steps added
+        width = int(eos_h.max()) + 1
+        ar = torch.arange(width, device=dv)[None, :]
+        probs = lps[:, :width].masked_fill(ar > where_eos[:, None], 0.0).reshape(bs, num_outputs, -1)
+        return res, probs.to(enc_input.device) if isinstance(enc_input, torch.Tensor) else probs
 
     # ------------------------------------------------------------------ search
     def beam_search(self, enc_input, enc_input_num_pads, sos_idx, eos_idx, beam_size=3, how_many_outputs=1,
@@ -181,8 +209,9 @@ class CaptioningModel(nn.Module):
         assert (sample_or_max == "max" or sample_or_max == "sample"), \
             "argument must be chosen between 'max' and 'sample'"
         mem = self.forward_enc(enc_input, enc_input_num_pads)
-        return self._search_from_memory(mem, enc_input_num_pads, sos_idx, eos_idx, beam_size, how_many_outputs,
-                                        max_seq_len, sample=(sample_or_max == "sample"))
+        toks, lp = self._search_from_memory(mem, enc_input_num_pads, sos_idx, eos_idx, beam_size, how_many_outputs,
+                                            max_seq_len, sample=(sample_or_max == "sample"))
+        return toks, (lp.to(enc_input.device) if isinstance(enc_input, torch.Tensor) else lp)
 
     def _search_from_memory(self, mem, enc_input_num_pads, sos_idx, eos_idx, beam_size, how_many_outputs,
                             max_seq_len, sample: bool = False) -> Tuple[List[List[List[int]]], torch.Tensor]:
@@ -197,16 +226,15 @@ class CaptioningModel(nn.Module):
         st.tokens[:, :, 0] = sos_idx
         st.next_tok.fill_(sos_idx)
         V = eng.g.vocab_size
-        logp = torch.empty(st.N, V, dtype=torch.float32, device=dv) if sample else None
+        seed = self._next_sampling_seed() if sample else 0
         for t in range(steps):
             if sample:
                 # 'sample' variant (captioning_model.py:128-131,166-168): the k candidates of every beam are
-                # drawn without replacement from its distribution instead of being its top-k
+                # drawn without replacement from its distribution instead of being its top-k — on the device
                 eng.step_logits(st)
-                ops.logsoftmax_topk(st.logits, V, logp, V, st.cand_val, st.cand_idx, st.N, V, 1)
-                draw = torch.multinomial(torch.exp(logp), k, replacement=False)
-                st.cand_idx.copy_(draw.to(torch.int32))
-                st.cand_val.copy_(logp.gather(1, draw))
+                ops.logsoftmax_sample(st.logits, V, None, 0, st.cand_val, st.cand_idx, st.N, V, k, seed, st.pos)
+                if self._draw_log is not None:                    # test hook: the draws, for replay in the oracle
+                    self._draw_log.append(st.cand_idx.cpu().clone())
                 ops.beam_step(st.cand_val, st.cand_idx, st.beam_state, st.n_img, st.beams, st.T, eos_idx)
             else:
                 eng.beam_step(st, eos_idx)

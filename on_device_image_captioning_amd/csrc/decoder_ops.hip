@@ -457,6 +457,105 @@ __global__ __launch_bounds__(1024) void logsoftmax_topk_kernel(const float* __re
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Sampling without replacement from softmax(x) — the `sample` branches of the reference search
+// (captioning_model.py:128-131,166-168: exp(log_probs).multinomial(k, replacement=False)) and the ancestral
+// sampling of :59-109 (k = 1) — as ONE pass over the row: the k largest of  x[v] + Gumbel(v)  are distributed
+// exactly as k sequential draws without replacement (Gumbel-top-k / Plackett-Luce), so no renormalisation loop
+// and no host round trip.  Noise: Philox4x32-10 keyed by `seed`, counter = (row, vocabulary index / 4, *pos, 0)
+// → reproducible for a given seed whatever the launch geometry; the position read from device memory makes a
+// captured step graph draw fresh numbers at every replay.  Outputs: the chosen words in draw order (descending
+// perturbed score) and their log-probabilities x[v] − logsumexp(x); optionally the full log-prob row.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float gumbel_from_bits(unsigned b) {
+  const float u = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);       // (0,1), 24 bits
+  return -logf(-logf(u));
+}
+
+template <int KM>
+__global__ __launch_bounds__(1024) void logsoftmax_sample_kernel(const float* __restrict__ logits, long ldl,
+                                                                 float* __restrict__ logp_out, long ldp,
+                                                                 float* __restrict__ top_val, int* __restrict__ top_idx,
+                                                                 int V, int k, unsigned long long seed,
+                                                                 const int* __restrict__ pos) {
+  __shared__ float red[16];
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  __shared__ int winner;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = logits + (long)n * ldl;
+  const unsigned step = pos ? (unsigned)*pos : 0u;
+  float tv[KM]; int ti[KM];
+#pragma unroll
+  for (int q = 0; q < KM; ++q) { tv[q] = -INFINITY; ti[q] = 0x7fffffff; }
+  float mx = -INFINITY;
+  // a thread owns groups of 4 consecutive words: one Philox call per group
+  for (int g4 = tid; g4 * 4 < V; g4 += 1024) {
+    unsigned r[4];
+    philox4x32_10((unsigned)n, (unsigned)g4, step, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int vi0 = g4 * 4 + e;
+      if (vi0 < V) {
+        const float xv = x[vi0];
+        mx = fmaxf(mx, xv);
+        float v = xv + gumbel_from_bits(r[e]); int vi = vi0;
+        if (v > tv[KM - 1]) {
+#pragma unroll
+          for (int q = 0; q < KM; ++q) {
+            if (v > tv[q]) { const float fv = tv[q]; const int fi = ti[q]; tv[q] = v; ti[q] = vi; v = fv; vi = fi; }
+          }
+        }
+      }
+    }
+  }
+  const float m = block_max(mx, red);
+  float s = 0.f;
+  for (int i = tid; i < V; i += 1024) s += expf(x[i] - m);
+  s = block_sum(s, red);
+  const float lse = m + logf(s);
+  if (logp_out)
+    for (int i = tid; i < V; i += 1024) logp_out[(long)n * ldp + i] = x[i] - lse;
+  for (int r = 0; r < k; ++r) {
+    float best = tv[0]; int besti = ti[0];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(besti, o, 64);
+      if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+      float b = bv[0]; int ix = bi[0];
+      for (int w = 1; w < 16; ++w)
+        if (bv[w] > b || (bv[w] == b && bi[w] < ix)) { b = bv[w]; ix = bi[w]; }
+      winner = ix;
+      top_val[(long)n * k + r] = x[ix] - lse;            // the word's log-probability, not its perturbed score
+      top_idx[(long)n * k + r] = ix;
+    }
+    __syncthreads();
+    if (ti[0] == winner) {
+#pragma unroll
+      for (int q = 0; q + 1 < KM; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
+      tv[KM - 1] = -INFINITY; ti[KM - 1] = 0x7fffffff;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Beam bookkeeping: one 64-lane block per image.  Lane 0 does the k·k selection, all lanes permute
 // the prefix / log-prob / ancestor rows IN PLACE (a lane owns whole columns j: it reads the k parent
@@ -814,5 +913,17 @@ extern "C" int odic_beam_reset(const odic_beam_state* st, int32_t n_img, int32_t
   hipLaunchKernelGGL(beam_reset_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      (long long*)st->tokens, st->logprobs, st->row_valid, (long long*)st->next_tok, st->pos, st->done,
                      st->ctr, N, T, (long long)sos_idx);
+  return odic_launch_status();
+}
+
+extern "C" int odic_logsoftmax_sample(const float* logits, int64_t ldl, float* logp_out, int64_t ldp, float* top_val,
+                                      int32_t* top_idx, int32_t N, int32_t V, int32_t k, uint64_t seed,
+                                      const int32_t* pos, void* stream) {
+  if (!logits || !top_val || !top_idx) return ODIC_ENULL;
+  if (N <= 0 || V <= 0 || k <= 0 || k > MAX_K || k > V) return ODIC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (k <= 4) hipLaunchKernelGGL(logsoftmax_sample_kernel<4>, dim3(N), dim3(1024), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k, (unsigned long long)seed, pos);
+  else if (k <= 8) hipLaunchKernelGGL(logsoftmax_sample_kernel<8>, dim3(N), dim3(1024), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k, (unsigned long long)seed, pos);
+  else hipLaunchKernelGGL(logsoftmax_sample_kernel<16>, dim3(N), dim3(1024), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k, (unsigned long long)seed, pos);
   return odic_launch_status();
 }

@@ -385,6 +385,16 @@ def logsoftmax_topk(logits, ldl, logp_out, ldp, top_val, top_idx, N, V, k) -> No
                                                     k, _stream()), "odic_logsoftmax_topk")
 
 
+def logsoftmax_sample(logits, ldl, logp_out, ldp, top_val, top_idx, N, V, k, seed: int, pos=None) -> None:
+    """k words per row drawn without replacement from softmax(logits) on the device (Gumbel-top-k, Philox noise
+    keyed by `seed`, the row, the word and *pos) + their log-probs — the reference's multinomial draws."""
+    _need_cuda(logits, logp_out, top_val, top_idx, pos)
+    with _timed("logsoftmax_topk", 14.0 * N * V, N * V * 4.0 * (2 if logp_out is not None else 1) + N * k * 8.0):
+        _hip.check(_hip.load().odic_logsoftmax_sample(_p(logits), ldl, _p(logp_out), ldp, _p(top_val), _p(top_idx), N, V,
+                                                      k, seed & 0xFFFFFFFFFFFFFFFF, _p(pos), _stream()),
+                   "odic_logsoftmax_sample")
+
+
 def ensemble_logprobs(logits_list, out: torch.Tensor) -> None:
     """out[n] = log(mean_m softmax(logits_m[n])) — ensemble_captioning_model.py:66-83."""
     _need_cuda(out, *logits_list)

@@ -282,9 +282,12 @@ def forward_teacher(sd: SD, g, enc_x, dec_x, enc_num_pads, dec_num_pads, log_sof
 
 def beam_search(sd, g, enc_x: torch.Tensor, enc_num_pads: Sequence[int], sos_idx: int,
                 eos_idx: int, beam_size: int = 3, how_many_outputs: int = 1, max_seq_len: int = 20,
-                end_to_end: bool = True, trace: list | None = None
+                end_to_end: bool = True, trace: list | None = None, draw_fn=None
                 ) -> Tuple[List[List[List[int]]], torch.Tensor]:
-    """captioning_model.py:111-241 ('max' branch), with plain tensors.
+    """captioning_model.py:111-241, with plain tensors.  `draw_fn=None` is the 'max' branch (top-k
+    candidates); `draw_fn(step, log_probs (rows, V)) -> LongTensor (rows, k)` supplies the candidate words of
+    the 'sample' branch (:128-131,166-168, where the reference calls multinomial) — tests inject the draws the
+    device made, so the bookkeeping around them can be compared exactly.
 
     `sd` may also be a LIST of state dicts: the ensemble search of ensemble_captioning_model.py:48-83 —
     every model encodes and decodes on its own, the per-step distribution is log(mean_m softmax(logits_m))
@@ -308,7 +311,11 @@ def beam_search(sd, g, enc_x: torch.Tensor, enc_num_pads: Sequence[int], sos_idx
 
     # ---- first step: one distribution per image, its top-k seed the beams (:117-140)
     lp0 = logprobs(mems, enc_num_pads, torch.full((B, 1), sos_idx, dtype=torch.long), [0] * B)[:, 0]
-    v0, w0 = torch.topk(lp0, k, dim=-1)
+    if draw_fn is None:
+        v0, w0 = torch.topk(lp0, k, dim=-1)
+    else:
+        w0 = draw_fn(0, lp0).long()
+        v0 = lp0.gather(-1, w0)
     toks = torch.stack([torch.full((B, k), sos_idx, dtype=torch.long), w0], -1)      # (B,k,2)
     lps = torch.stack([torch.zeros(B, k), v0], -1)
     cumul = lps.sum(-1)
@@ -319,7 +326,11 @@ def beam_search(sd, g, enc_x: torch.Tensor, enc_num_pads: Sequence[int], sos_idx
 
     for t in range(2, max_seq_len):
         lp = logprobs(mems_k, pads_k, toks.reshape(B * k, t), (t - n_elem).reshape(-1).tolist())[:, t - 1]
-        cv, cw = torch.topk(lp, k, dim=-1)                                  # (B*k, k)
+        if draw_fn is None:
+            cv, cw = torch.topk(lp, k, dim=-1)                              # (B*k, k)
+        else:
+            cw = draw_fn(t - 1, lp).long()
+            cv = lp.gather(-1, cw)
         cv, cw = cv.view(B, k, k).clone(), cw.view(B, k, k)
         done = (toks == eos_idx).any(-1)                                    # (B,k)
         cv[:, :, 0] = torch.where(done, torch.zeros(()), cv[:, :, 0])       # keep score (:193)

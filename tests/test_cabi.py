@@ -53,6 +53,21 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.odic_gemm(ctypes.byref(a), None) == -1
     assert lib.odic_layernorm(None, 0, None, None, None, 1, 4, 1e-5, 0, None) == -2
     assert lib.odic_window_attention(16, 16, None, 16, 1, 12, 100, 3, 12, 0, 1.0, 1, None) == -1   # heads*32 != C
+    # odic_beam_step: per-token log-probs are staged in LDS for at most 128 positions, and the arrival counter
+    # packs {arrivals, growing images} into one int32: both limits are rejected, not overrun
+    st = _hip.BeamState(*([16] * 11))
+    assert lib.odic_beam_step(16, 16, ctypes.byref(st), 4, 3, 129, 77, None) == -1
+    assert lib.odic_beam_step(16, 16, ctypes.byref(st), 32768, 3, 20, 77, None) == -1
+    assert lib.odic_beam_step(16, 16, ctypes.byref(st), 4, 17, 20, 77, None) == -1
+    assert lib.odic_beam_reset(None, 4, 3, 20, 79, None) == -2
+    assert lib.odic_beam_finalize_best(ctypes.byref(st), 16, 16, None, 16, 4, 3, 20, 77, None) == -2
+    assert lib.odic_logsoftmax_sample(16, 8, None, 0, 16, 16, 4, 8, 9, 0, None, None) == -1           # k > V
+    # persistent bf16 tile configurations need the caller's workspace
+    a = _hip.GemmArgs()
+    a.A, a.W, a.out = 16, 16, 16
+    a.M, a.N, a.K, a.batch, a.lda, a.ldw, a.ldc = 256, 256, 64, 1, 64, 64, 256
+    a.in_dtype, a.out_dtype, a.tile_cfg = _hip.BF16, _hip.BF16, 17
+    assert lib.odic_gemm(ctypes.byref(a), None) == -1
 
 
 def test_product_path_has_no_cpu_fallback():
@@ -63,10 +78,11 @@ def test_product_path_has_no_cpu_fallback():
     g = W.TINY
     m = End_ExpansionNet_v2(**g.model_kwargs(), output_word2idx={i: i for i in range(g.vocab_size)},
                             output_idx2word=list(range(g.vocab_size)), drop_args=make_drop_args(), rank="cpu")
-    with pytest.raises(RuntimeError, match="no CPU"):
-        m(enc_x=W.synth_images(1, g), enc_x_num_pads=[0], mode="beam_search", sos_idx=3, eos_idx=2)
-    with pytest.raises(RuntimeError, match="no CPU"):
-        m.forward_enc(W.synth_images(1, g), [0])
+    if not torch.cuda.is_available():          # (with a GPU a host-resident model runs on it: tests/test_e2e_gpu.py)
+        with pytest.raises(RuntimeError, match="no CPU"):
+            m(enc_x=W.synth_images(1, g), enc_x_num_pads=[0], mode="beam_search", sos_idx=3, eos_idx=2)
+        with pytest.raises(RuntimeError, match="no CPU"):
+            m.forward_enc(W.synth_images(1, g), [0])
 
 
 def test_reference_api_surface():
@@ -104,3 +120,23 @@ def test_preprocess_matches_recorded_checksums():
         assert tuple(t.shape) == (1, 3, 384, 384) and t.dtype == torch.float32
         assert abs(float(t.double().sum()) - want["sum"]) < 1e-2
         assert abs(float(t.double().abs().sum()) - want["abssum"]) < 1e-2
+
+
+def test_preprocess_non_rgb_becomes_a_black_canvas(tmp_path):
+    """utils/image_utils.py:18-19: a file whose mode is not RGB is REPLACED by PIL_Image.new('RGB', size) — an
+    all-black image, not a conversion — before Resize / ToTensor / Normalize.  Grey-scale, RGBA and palette files
+    all map to the same tensor, the normalised zero image."""
+    from PIL import Image
+    from on_device_image_captioning_amd.image_utils import preprocess_image
+    import numpy as np
+    rng = np.random.default_rng(0)
+    want = ((torch.zeros(3) - torch.tensor([0.485, 0.456, 0.406])) / torch.tensor([0.229, 0.224, 0.225]))
+    for mode, shape, ext in (("L", (50, 70), "png"), ("RGBA", (40, 60, 4), "png"), ("P", (30, 30), "png")):
+        path = str(tmp_path / f"img_{mode}.{ext}")
+        Image.fromarray(rng.integers(1, 255, size=shape, dtype=np.uint8), "L" if mode == "P" else mode).convert(mode).save(path)
+        t = preprocess_image(path, 96)
+        assert tuple(t.shape) == (1, 3, 96, 96) and t.dtype == torch.float32
+        assert torch.equal(t, want.view(1, 3, 1, 1).expand(1, 3, 96, 96))
+    rgb = str(tmp_path / "rgb.png")
+    Image.fromarray(rng.integers(1, 255, size=(20, 20, 3), dtype=np.uint8), "RGB").save(rgb)
+    assert not torch.equal(preprocess_image(rgb, 96), want.view(1, 3, 1, 1).expand(1, 3, 96, 96))

@@ -407,3 +407,155 @@ def test_gemm_bf16_persistent_many_tiles_per_block(ops, cfg):
         ws = ops._gemm_workspace(dA.device)
         torch.cuda.synchronize()
         assert int(ws.abs().sum()) == 0                    # counters left at zero
+
+
+# ------------------------------------------------------------------------------------------ beam bookkeeping, directly
+def _beam_state(ops, n_img, k, T):
+    from on_device_image_captioning_amd import _hip
+    N = n_img * k
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device="cuda")      # noqa: E731
+    t = dict(tokens=z(n_img, k, T, dt=torch.int64), logprobs=z(n_img, k, T), anc=z(N, T, dt=torch.int32), cumul=z(N),
+             n_elem=z(N, dt=torch.int32), has_eos=z(N, dt=torch.int32), row_valid=z(N, dt=torch.int32),
+             next_tok=z(N, dt=torch.int64), pos=z(1, dt=torch.int32), done=z(1, dt=torch.int32), ctr=z(1, dt=torch.int32))
+    st = _hip.BeamState(*(t[n].data_ptr() for n in ("tokens", "logprobs", "anc", "cumul", "n_elem", "has_eos",
+                                                    "row_valid", "next_tok", "pos", "done", "ctr")))
+    return t, st
+
+
+def test_beam_step_direct_against_the_search_loop(ops):
+    """odic_beam_reset / odic_beam_step / odic_beam_finalize(_best) on synthetic candidate tables, step by step
+    against a plain restatement of captioning_model.py:117-241: EXACT ties in the k·k selection (lowest flat
+    index wins, the scan order of torch.topk on sorted input), finished beams (0.0 / −999 masking, frozen length),
+    re-summed cumulative scores, the ancestor table, the all-finished fixed point over the remaining steps,
+    `done`, and the arrival counter re-armed after every step and across a second search on the same state."""
+    n_img, k, T, sos, eos = 6, 3, 14, 5, 7
+    N = n_img * k
+    rng = np.random.default_rng(3)
+    t, st = _beam_state(ops, n_img, k, T)
+    for search in range(2):
+        ops.beam_reset(st, n_img, k, T, sos)
+        toks = [[[sos] for _ in range(k)] for _ in range(n_img)]
+        lps = [[[np.float32(0.0)] for _ in range(k)] for _ in range(n_img)]
+        n_elem = [[1] * k for _ in range(n_img)]
+        anc = np.zeros((N, T), dtype=np.int64)
+        all_done_at = None
+        for step in range(T - 1):
+            # candidates: log-probs on a coarse grid (→ exact ties across beams), sorted descending per row;
+            # EOS is frequent from step 3 on so that every beam finishes well before T
+            cv = -np.sort(rng.integers(1, 6, size=(N, k)).astype(np.float32) * 0.25, axis=1)
+            cw = rng.integers(10, 40, size=(N, k)).astype(np.int32)
+            if step >= 3:
+                cw[rng.random((N, k)) < 0.45] = eos
+            ops.beam_step(dev(torch.from_numpy(cv)), dev(torch.from_numpy(cw)), st, n_img, k, T, eos)
+            new_toks, new_lps, new_ne, valid, nxt = [], [], [], [], []
+            new_anc = anc.copy()
+            for b in range(n_img):
+                if step == 0:
+                    sel = [(0, c) for c in range(k)]
+                    val = {(0, c): cv[b * k, c] for c in range(k)}
+                else:
+                    tot, val = [], {}
+                    for j in range(k):
+                        dn = eos in toks[b][j]
+                        cu = np.float32(0.0)
+                        for x in lps[b][j]:
+                            cu = np.float32(cu + x)
+                        for c in range(k):
+                            v = (np.float32(0.0) if c == 0 else np.float32(-999.0)) if dn else cv[b * k + j, c]
+                            val[(j, c)] = v
+                            tot.append((np.float32(cu + v), j, c))
+                    sel = []
+                    for _ in range(k):
+                        bi = max(range(len(tot)), key=lambda i: (tot[i][0], -i))        # ties → lowest flat index
+                        sel.append((tot[bi][1], tot[bi][2]))
+                        tot[bi] = (np.float32(-np.inf), 0, 0)
+                rt, rl, rn = [], [], []
+                for r, (j, c) in enumerate(sel):
+                    had = (eos in toks[b][j]) if step > 0 else False
+                    w = int(cw[b * k + j, c])
+                    rt.append(toks[b][j] + [w])
+                    rl.append(lps[b][j] + [val[(j, c)]])
+                    rn.append((n_elem[b][j] if step > 0 else 1) + (0 if had else 1))
+                    valid.append(0 if had else 1)
+                    nxt.append(w)
+                    new_anc[b * k + r, :step] = anc[b * k + j, :step]
+                    new_anc[b * k + r, step] = b * k + j
+                new_toks.append(rt); new_lps.append(rl); new_ne.append(rn)
+            toks, lps, n_elem, anc = new_toks, new_lps, new_ne, new_anc
+            L = step + 2
+            got_tok = t["tokens"].cpu().numpy()[:, :, :L]
+            assert got_tok.tolist() == toks, f"search {search} step {step}: prefixes"
+            np.testing.assert_array_equal(t["logprobs"].cpu().numpy()[:, :, :L], np.array(lps, dtype=np.float32))
+            cum = [[np.float32(0.0)] * k for _ in range(n_img)]
+            for b in range(n_img):
+                for j in range(k):
+                    c = np.float32(0.0)
+                    for x in lps[b][j]:
+                        c = np.float32(c + x)
+                    cum[b][j] = c
+            np.testing.assert_array_equal(t["cumul"].cpu().numpy().reshape(n_img, k), np.array(cum, dtype=np.float32))
+            assert t["n_elem"].cpu().numpy().reshape(n_img, k).tolist() == n_elem
+            assert t["has_eos"].cpu().numpy().reshape(n_img, k).tolist() == [[int(eos in s_) for s_ in row] for row in toks]
+            assert t["row_valid"].cpu().tolist() == valid and t["next_tok"].cpu().tolist() == nxt
+            np.testing.assert_array_equal(t["anc"].cpu().numpy()[:, :step + 1], anc[:, :step + 1])
+            assert int(t["pos"]) == step + 1 and int(t["ctr"]) == 0
+            nothing_grew = all(v == 0 for v in valid)
+            if nothing_grew and all_done_at is None:
+                all_done_at = step
+                frozen = ([row[:] for row in n_elem], [row[:] for row in cum])
+            assert int(t["done"]) == int(all_done_at is not None)
+            if all_done_at is not None:                         # fixed point: lengths and scores no longer move
+                assert n_elem == frozen[0] and cum == frozen[1]
+        assert all_done_at is not None and all_done_at < T - 3   # the fixture does exercise the fixed point
+        order = torch.empty(n_img, k, dtype=torch.int32, device="cuda")
+        score = torch.empty(n_img, k, dtype=torch.float32, device="cuda")
+        out_tok = torch.empty(n_img, T, dtype=torch.int32, device="cuda")
+        out_len = torch.empty(n_img, dtype=torch.int32, device="cuda")
+        ops.beam_finalize_best(st, order, score, out_tok, out_len, n_img, k, T, eos)
+        order2, score2 = torch.empty_like(order), torch.empty_like(score)
+        ops.beam_finalize(st, order2, score2, n_img, k)
+        assert torch.equal(order, order2) and torch.equal(score, score2)
+        for b in range(n_img):
+            sc = [np.float32(cum[b][j] / np.float32(n_elem[b][j])) for j in range(k)]
+            want_order = sorted(range(k), key=lambda j: (-sc[j], j))
+            assert order[b].tolist() == want_order
+            best = want_order[0]
+            n = n_elem[b][best]
+            assert int(out_len[b]) == n
+            assert out_tok[b].tolist() == toks[b][best][:n] + [eos] * (T - n)
+
+
+def test_logsoftmax_sample_draws_follow_the_distribution(ops):
+    """odic_logsoftmax_sample: k draws without replacement per row (Gumbel-top-k on the device).  Over 40,000 rows
+    of one 12-word distribution: no duplicates in a row, reported values = log-probs of the drawn words, the first
+    draw's frequencies match softmax(x) and the second draw's match the exact without-replacement marginal (4 sigma);
+    same seed → same draws, another seed or position → different draws."""
+    V, k, N = 12, 3, 40000
+    x = rnd(V, seed=4, scale=1.3)
+    logits = dev(x[None, :].expand(N, V).contiguous())
+    val = torch.empty(N, k, device="cuda")
+    idx = torch.empty(N, k, dtype=torch.int32, device="cuda")
+    pos = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.logsoftmax_sample(logits, V, None, 0, val, idx, N, V, k, 1234, pos)
+    I = idx.cpu().long()
+    logp = torch.log_softmax(x.double(), 0)
+    assert_close(val, logp[I].float(), 2e-6, "log-probs of the drawn words")
+    assert bool(((I[:, 0] != I[:, 1]) & (I[:, 0] != I[:, 2]) & (I[:, 1] != I[:, 2])).all())
+    p = logp.exp()
+    f1 = torch.bincount(I[:, 0], minlength=V).double() / N
+    assert float(((f1 - p).abs() / (p * (1 - p) / N).sqrt()).max()) < 4.0
+    p2 = torch.stack([sum(p[a] * p[b] / (1 - p[a]) for a in range(V) if a != b) for b in range(V)])
+    f2 = torch.bincount(I[:, 1], minlength=V).double() / N
+    assert float(((f2 - p2).abs() / (p2 * (1 - p2) / N).sqrt()).max()) < 4.0
+    idx2 = torch.empty_like(idx)
+    ops.logsoftmax_sample(logits, V, None, 0, val, idx2, N, V, k, 1234, pos)
+    assert torch.equal(idx, idx2)
+    ops.logsoftmax_sample(logits, V, None, 0, val, idx2, N, V, k, 1235, pos)
+    assert not torch.equal(idx, idx2)
+    pos.fill_(3)
+    ops.logsoftmax_sample(logits, V, None, 0, val, idx2, N, V, k, 1234, pos)
+    assert not torch.equal(idx, idx2)
+    full = torch.empty(4, 10000, device="cuda")                    # the vocabulary-sized row + the log-prob output
+    lg = dev(rnd(4, 10000, seed=8))
+    ops.logsoftmax_sample(lg, 10000, full, 10000, val[:4], idx[:4], 4, 10000, k, 5, None)
+    assert_close(full, torch.log_softmax(lg.double().cpu(), -1), 2e-6, "logp_out")
