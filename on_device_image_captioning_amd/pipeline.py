@@ -57,10 +57,15 @@ class CaptionPipeline:
         self.NB = self.G * batch                                   # images per search launch
         self.RG = self.D + 1                                       # result ring, in groups
         self.R = self.RG * self.G                                  # batches that may be outstanding (upper bound)
-        if hasattr(model, "swin_transf"):
-            swin, cap = model._engines()
-        else:
-            swin, cap = None, model._captioner_engine()
+        # members: one (backbone engine, captioner engine) pair per model; an EsembleCaptioningModel contributes
+        # all of its models (every member encodes and decodes on its own, ONE shared beam state per lane,
+        # per-step distribution = log(mean softmax) — ensemble_captioning_model.py:66-83)
+        models = list(getattr(model, "models_list", None) or [model])
+        self.members = [m._engines() if hasattr(m, "swin_transf") else (None, m._captioner_engine()) for m in models]
+        self.M = len(self.members)
+        swin, cap = self.members[0]
+        if any((sw is None) != (swin is None) or c.g != cap.g for sw, c in self.members):
+            raise RuntimeError("ensemble members must share one geometry and input kind")
         self.swin, self.cap = swin, cap
         g, dv = cap.g, cap.device
         self.device = dv
@@ -77,11 +82,19 @@ class CaptionPipeline:
         self.enc_len_grps = [torch.full((self.NB,), S, dtype=torch.int32, device=dv) for _ in range(self.D)]
         self.host_len_in = [torch.full((batch,), S, dtype=torch.int32).pin_memory() for _ in range(self.E)]
         nkv = 2 * g.N_dec * g.d_model
-        self.kv_stages = [torch.empty(batch, S, nkv, dtype=torch.float32, device=dv)    # written by the encode graphs
-                          for _ in range(self.E)]
-        self.kv = [torch.empty(self.NB, S, nkv, dtype=torch.float32, device=dv) for _ in range(self.D)]
-        self.states = [cap.new_state(self.NB, beam_size, self.T, self.kv[l], self.enc_len_grps[l])
-                       for l in range(self.D)]
+        # K/V of every member: [member] stacked in the leading dim, written by the encode graphs
+        self.kv_stages = [torch.empty(self.M, batch, S, nkv, dtype=torch.float32, device=dv) for _ in range(self.E)]
+        self.kv = [torch.empty(self.M, self.NB, S, nkv, dtype=torch.float32, device=dv) for _ in range(self.D)]
+        self.member_states = []                                    # [lane][member]; member 0 owns the beam state
+        for l in range(self.D):
+            sts = [c.new_state(self.NB, beam_size, self.T, self.kv[l][mi], self.enc_len_grps[l])
+                   for mi, (_, c) in enumerate(self.members)]
+            for st in sts[1:]:
+                st.anc, st.row_valid, st.next_tok, st.pos = sts[0].anc, sts[0].row_valid, sts[0].next_tok, sts[0].pos
+            self.member_states.append(sts)
+        self.states = [sts[0] for sts in self.member_states]
+        self.avg_logp = [torch.empty(self.NB * beam_size, g.vocab_size, dtype=torch.float32, device=dv)
+                         for _ in range(self.D)] if self.M > 1 else None
         self.order = [torch.empty(self.NB, beam_size, dtype=torch.int32, device=dv) for _ in range(self.D)]
         self.score = [torch.empty(self.NB, beam_size, dtype=torch.float32, device=dv) for _ in range(self.D)]
         if streams is not None:                                    # ([encode streams], [decode streams]) supplied by the caller
@@ -136,15 +149,25 @@ class CaptionPipeline:
 
     # -- the captured regions -------------------------------------------------------------------
     def _encode(self, e: int = 0) -> None:
-        feats = self.swin.forward(self.imgs[e], out_dtype=self.cap.cdt) if self.swin is not None else self.imgs[e]
-        if self.cap.cdt == torch.bfloat16:
-            _, mem16 = self.cap.encode(feats, self.enc_lens[e], want_bf16_mem=True)
-            self.cap.project_kv(mem16, out=self.kv_stages[e])
-        else:
-            self.cap.project_kv(self.cap.encode(feats, self.enc_lens[e]), out=self.kv_stages[e])
+        for mi, (swin, cap) in enumerate(self.members):
+            feats = swin.forward(self.imgs[e], out_dtype=cap.cdt) if swin is not None else self.imgs[e]
+            if cap.cdt == torch.bfloat16:
+                _, mem16 = cap.encode(feats, self.enc_lens[e], want_bf16_mem=True)
+                cap.project_kv(mem16, out=self.kv_stages[e][mi])
+            else:
+                cap.project_kv(cap.encode(feats, self.enc_lens[e]), out=self.kv_stages[e][mi])
 
     def _step(self, lane: int) -> None:
-        self.cap.beam_step(self.states[lane], self.eos)
+        if self.M == 1:
+            self.cap.beam_step(self.states[lane], self.eos)
+            return
+        sts = self.member_states[lane]
+        lead = sts[0]
+        for (_, cap), st in zip(self.members, sts):
+            cap.step_logits(st)                                   # private caches, shared next_tok / pos / ancestors
+        ops.ensemble_logprobs([st.logits for st in sts], self.avg_logp[lane])
+        ops.topk_rows(self.avg_logp[lane], lead.cand_val, lead.cand_idx, lead.beams)
+        ops.beam_step(lead.cand_val, lead.cand_idx, lead.beam_state, lead.n_img, lead.beams, lead.T, self.eos)
 
     def _reset(self, lane: int) -> None:
         st = self.states[lane]
@@ -158,7 +181,7 @@ class CaptionPipeline:
             with torch.cuda.stream(self.s_dec[lane]):
                 self.s_dec[lane].wait_stream(self.s_encs[0])
                 for p in range(self.G):
-                    self.kv[lane][p * self.B:(p + 1) * self.B].copy_(self.kv_stages[0])
+                    self.kv[lane][:, p * self.B:(p + 1) * self.B].copy_(self.kv_stages[0])
                 self._reset(lane)
                 self._step(lane)
         torch.cuda.synchronize()
@@ -210,7 +233,7 @@ class CaptionPipeline:
         sd = self.s_dec[lane]
         with torch.cuda.stream(sd):
             sd.wait_event(self.ev_enc[e])
-            self.kv[lane][gpos * self.B:(gpos + 1) * self.B].copy_(self.kv_stages[e])
+            self.kv[lane][:, gpos * self.B:(gpos + 1) * self.B].copy_(self.kv_stages[e])
             if self.swin is None:
                 self.enc_len_grps[lane][gpos * self.B:(gpos + 1) * self.B].copy_(self.enc_lens[e])
             self.ev_kv_taken[e].record()
@@ -234,7 +257,7 @@ class CaptionPipeline:
         st = self.states[lane]
         with torch.cuda.stream(self.s_dec[lane]):
             for p in range(filled, self.G):
-                self.kv[lane][p * self.B:(p + 1) * self.B].copy_(self.kv[lane][(filled - 1) * self.B:filled * self.B])
+                self.kv[lane][:, p * self.B:(p + 1) * self.B].copy_(self.kv[lane][:, (filled - 1) * self.B:filled * self.B])
                 if self.swin is None:
                     self.enc_len_grps[lane][p * self.B:(p + 1) * self.B].copy_(
                         self.enc_len_grps[lane][(filled - 1) * self.B:filled * self.B])

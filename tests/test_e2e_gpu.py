@@ -665,3 +665,77 @@ def test_demo_flow_with_a_host_resident_model(tmp_path):
     text = tokens2description(pred[0][0], idx2word, sos_idx, eos_idx)
     assert text == R.tokens2description(want[0][0], idx2word, sos_idx, eos_idx)
     assert text[0].isupper() and text.endswith(".")
+
+
+# ----------------------------------------------------------------------------------------- F4: layer-removed variants
+@pytest.mark.parametrize("cfg", [1, 2])
+def test_layer_removed_variants_match_reference(cfg):
+    """`--param_config 1` (N_enc = 2) and `2` (N_enc = N_dec = 2), reference test.py:360-365: model built with the
+    reduced layer counts, the 3-layer checkpoint folded through checkpoint_utils.load_state_dict_filtered
+    (test.py:38-77), captions against the REFERENCE's 2-layer classes on the same folded dict — end to end at the
+    TINY geometry and features-only at the full captioner geometry with ragged encoder pads."""
+    from dataclasses import replace
+    from on_device_image_captioning_amd.checkpoint_utils import load_state_dict_filtered
+    from on_device_image_captioning_amd.End_ExpansionNet_v2 import End_ExpansionNet_v2, make_drop_args
+    from on_device_image_captioning_amd.ExpansionNet_v2 import ExpansionNet_v2
+    ne, nd, mode = {1: (2, 3, "enc"), 2: (2, 2, "dec")}[cfg]
+    g3 = replace(W.TINY, N_enc=3, N_dec=3)
+    g = replace(g3, N_enc=ne, N_dec=nd)
+    ckpt = {"model_state_dict": W.synth_state_dict(g3, variant="eos", eos_idx=TEOS)}
+    m = End_ExpansionNet_v2(**g.model_kwargs(), output_word2idx={i: i for i in range(g.vocab_size)},
+                            output_idx2word=list(range(g.vocab_size)), drop_args=make_drop_args(), rank=DEV)
+    load_state_dict_filtered(m, ckpt, mode)
+    m.to(DEV).eval()
+    store = np.load(os.path.join(GOLDEN, "tiny_variants.npz"))
+    img = W.synth_images(3, g).to(DEV)
+    check_sample(store, f"cfg{cfg}.enc_out", m.forward_enc(img, [0] * 3), 2e-4)
+    for k, T in ((1, 12), (3, 16)):
+        toks, lps = m(enc_x=img, enc_x_num_pads=[0] * 3, mode="beam_search", beam_size=k, how_many_outputs=1,
+                      beam_max_seq_len=T, sample_or_max="max", sos_idx=TSOS, eos_idx=TEOS)
+        assert toks == unpad(store[f"cfg{cfg}.beam{k}_T{T}.tokens"])
+        np.testing.assert_allclose(lps.cpu().numpy(), store[f"cfg{cfg}.beam{k}_T{T}.logprobs"], atol=1e-3)
+    # features-only, full captioner geometry
+    gf = replace(W.FULL, N_enc=ne, N_dec=nd)
+    ckpt = {"model_state_dict": W.synth_state_dict(W.FULL, variant="xavier", end_to_end=False, img_feature_dim=1536)}
+    mf = ExpansionNet_v2(d_model=gf.d_model, N_enc=ne, N_dec=nd, ff=gf.ff, num_heads=gf.num_heads,
+                         num_exp_enc_list=list(gf.num_exp_enc_list), num_exp_dec=gf.num_exp_dec,
+                         output_word2idx={i: i for i in range(gf.vocab_size)}, output_idx2word=list(range(gf.vocab_size)),
+                         max_seq_len=gf.max_seq_len, drop_args=make_drop_args(), img_feature_dim=1536, rank=DEV)
+    load_state_dict_filtered(mf, ckpt, mode)
+    mf.to(DEV).eval()
+    storef = np.load(os.path.join(GOLDEN, "full_variants.npz"))
+    feats = W.synth_features(4, 144, 1536, seed=77).to(DEV)
+    toks, lps = mf(enc_x=feats, enc_x_num_pads=[0, 5, 0, 17], mode="beam_search", beam_size=3, how_many_outputs=1,
+                   beam_max_seq_len=20, sample_or_max="max", sos_idx=SOS, eos_idx=EOS)
+    assert toks == unpad(storef[f"cfg{cfg}.beam3_T20.tokens"])
+    np.testing.assert_allclose(lps.cpu().numpy(), storef[f"cfg{cfg}.beam3_T20.logprobs"], atol=2e-3)
+
+
+@pytest.mark.parametrize("name", ["two", "three"])
+def test_ensemble_on_the_graph_pipeline_matches_reference(name):
+    """EsembleCaptioningModel through CaptionPipeline: every member's encode pass in the encode graph, every member's
+    decoder step + odic_ensemble_logprobs + odic_topk_rows + odic_beam_step in ONE step graph per lane, two lanes,
+    several batches in flight — best caption per image = the reference ensemble search's (tiny_ensemble.npz)."""
+    from on_device_image_captioning_amd.End_ExpansionNet_v2 import End_ExpansionNet_v2, make_drop_args
+    from on_device_image_captioning_amd.ensemble_captioning_model import EsembleCaptioningModel
+    from on_device_image_captioning_amd.pipeline import CaptionPipeline
+    store = np.load(os.path.join(GOLDEN, "tiny_ensemble.npz"))
+    g = W.TINY
+    members = []
+    for s_, v_ in zip(store[name + ".seeds"], store[name + ".variants"]):
+        m = End_ExpansionNet_v2(**g.model_kwargs(), output_word2idx={i: i for i in range(g.vocab_size)},
+                                output_idx2word=list(range(g.vocab_size)), drop_args=make_drop_args(), rank=DEV)
+        m.load_state_dict(W.synth_state_dict(g, seed=int(s_), variant=str(v_), eos_idx=TEOS), strict=True)
+        members.append(m.to(DEV).eval())
+    ens = EsembleCaptioningModel(members, DEV)
+    img = W.synth_images(3, g).to(DEV)
+    want = [per[0] for per in unpad(store[f"{name}.beam3_T12.tokens"])]
+    pipe = CaptionPipeline(ens, 3, 3, 12, TSOS, TEOS, done_poll=4)
+    assert pipe.M == len(members)
+    pipe.submit(img)
+    pipe.submit(img.flip(0).contiguous())
+    pipe.submit(img)
+    assert pipe.collect() == want
+    assert pipe.collect() == want[::-1]
+    assert pipe.collect() == want
+    assert pipe(img.flip(0).contiguous()) == want[::-1]

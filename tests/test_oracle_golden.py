@@ -252,3 +252,32 @@ def test_caption_cleaner_matches_reference_strings():
     i2w = sorted(g["word2idx"], key=g["word2idx"].get)
     assert L.convert_allsentences_idx2word(ids, i2w) == g["convert_allsentences_idx2word"]
     assert L.clean_captions(raw) == [" ".join(t) for t in g["tokenize"]]
+
+
+# ----------------------------------------------------------------------------------- F4: layer-removed variants
+def test_layer_removed_checkpoint_folding_and_oracle():
+    """`--param_config 1/2` (test.py:360-365): the 3-layer checkpoint folded by the rules of test.py:38-77 and run
+    by the oracle's 2-layer model gives the captions the REFERENCE's 2-layer classes gave on the same folded
+    dict (tests/golden/tiny_variants.npz, oracle/make_golden_variants.py)."""
+    from dataclasses import replace
+    from on_device_image_captioning_amd.checkpoint_utils import filter_state_dict
+    g3 = replace(W.TINY, N_enc=3, N_dec=3)
+    sd3 = W.synth_state_dict(g3, variant="eos", eos_idx=TEOS)
+    e = filter_state_dict(sd3, "enc")
+    d = filter_state_dict(sd3, "dec")
+    assert not any(k.startswith("encoders.2") for k in e) and any(k.startswith("decoders.2") for k in e)
+    assert not any(k.startswith(("encoders.2", "decoders.2")) for k in d)
+    assert torch.equal(e["encoders.1.ff.linear_1.weight"], sd3["encoders.2.ff.linear_1.weight"])   # layer 2 replaces 1
+    assert torch.equal(d["decoders.1.mha.Wq.weight"], sd3["decoders.2.mha.Wq.weight"])
+    dm = g3.d_model
+    w = sd3["enc_reduce_group.weight"]
+    assert torch.equal(e["enc_reduce_group.weight"], torch.cat([w[:, :dm], w[:, 2 * dm:]], 1))
+    assert e["dec_reduce_group.weight"].shape == (dm, 3 * dm) and d["dec_reduce_group.weight"].shape == (dm, 2 * dm)
+    store = np.load(os.path.join(GOLDEN, "tiny_variants.npz"))
+    img = W.synth_images(3, g3)
+    for cfg, (ne, nd, sd) in {1: (2, 3, e), 2: (2, 2, d)}.items():
+        g = replace(g3, N_enc=ne, N_dec=nd)
+        check_sample(store, f"cfg{cfg}.enc_out", R.forward_enc(sd, g, img, [0] * 3))
+        toks, lps = R.beam_search(sd, g, img, [0] * 3, TSOS, TEOS, 3, 1, 16)
+        assert toks == unpad(store[f"cfg{cfg}.beam3_T16.tokens"])
+        np.testing.assert_allclose(lps.numpy(), store[f"cfg{cfg}.beam3_T16.logprobs"], atol=5e-5)

@@ -59,7 +59,7 @@ for s in range(4):
 gr = torch.cuda.CUDAGraph()
 with torch.cuda.graph(gr, stream=s_enc):
     _, mem16 = cap.encode(feats, pipe.enc_lens[0], want_bf16_mem=True)
-    cap.project_kv(mem16, out=pipe.kv_stage)
+    cap.project_kv(mem16, out=pipe.kv_stage[0])
 graphs.append(gr); names.append("expansion encoder + K/V")
 torch.cuda.synchronize()
 
