@@ -40,7 +40,7 @@ extern "C" {
 #define ODIC_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ODIC_ABI_VERSION 8
+#define ODIC_ABI_VERSION 9
 int odic_abi_version(void);
 
 /* Human-readable build string ("gfx950 hipcc ..."), static storage. */
@@ -138,15 +138,17 @@ int odic_resize_bilinear_normalize(const uint8_t* src_rgb, int32_t H, int32_t W,
  *   qkv  `dtype` [B*res*res, 3C]   token-major output of the qkv Linear, columns (3, heads, 32)
  *   bias_table fp32 [(2ws-1)², heads]   relative_position_bias_table; the index buffer (:163-173)
  *        and the SW-MSA mask (:281-297, values 0/-100) are recomputed from coordinates.
- *   bias_dense_prescaled (optional, bf16 path) fp32 [heads, ws², ws²] = bias_table[relative_position_index]
- *        (the gather of :196-198) DIVIDED BY `scale`: the fast kernel loads it as the accumulator
- *        init of the q·kᵀ MFMA and applies scale·log2(e) afterwards (base-2 softmax, no bias
- *        arithmetic, no index arithmetic).  NULL → the table is used.
+ *   bias_shifted_prescaled (optional, bf16 path, ws = 12) fp32 [heads, 4, 576]: per head four copies of the
+ *        x-reversed bias table with rows padded to 24, R[r·24 + c'] = bias_table[r·23 + (22 - c')] / scale,
+ *        copy s holding R shifted by s floats (copy_s[i] = R[i + s]) — the four keys of an accumulator quad
+ *        are then ONE aligned 16-byte LDS read (the gather of :196-198 without a dense [ws², ws²] tensor).
+ *        The fast kernel keeps the 9 KiB in LDS, loads the bias as the accumulator init of the q·kᵀ MFMA and
+ *        applies scale·log2(e) afterwards (base-2 softmax).  NULL → the table is used (slower kernel).
  *   out  `dtype` [B*res*res, C]    softmax(q·kᵀ·scale + bias + mask)·v, heads concatenated,
  *        written back at the un-shifted token positions (ready for the proj Linear).
  * head_dim is 32 (every Swin-L stage), ws*ws <= 144, res % ws == 0, 0 <= shift < ws.
  * ------------------------------------------------------------------------------------------- */
-int odic_window_attention(const void* qkv, const float* bias_table, const float* bias_dense_prescaled,
+int odic_window_attention(const void* qkv, const float* bias_table, const float* bias_shifted_prescaled,
                           void* out, int32_t B, int32_t res, int32_t C, int32_t heads, int32_t ws,
                           int32_t shift, float scale, int32_t dtype, void* stream);
 

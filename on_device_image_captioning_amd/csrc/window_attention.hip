@@ -29,7 +29,7 @@ constexpr int HD = 32;        // head dim of every Swin-L stage
 constexpr int MAXN = 144;     // ws*ws upper bound
 
 struct WinParams {
-  const void* qkv; const float* table; const float* bias_dense; void* out;
+  const void* qkv; const float* table; const float* bias_shifted; void* out;
   int B, res, C, heads, ws, shift, nwin_side;
   float scale;
 };
@@ -291,28 +291,35 @@ __global__ __launch_bounds__(192, 2) void window_attention_bf16_kernel(WinParams
 
 
 // =================================================================================================
-// bf16 MFMA kernel, v2 (used when the caller supplies the dense pre-scaled bias).  The kernel is
-// VALU-issue-bound (36 scores per lane and query tile: v_exp_f32 alone is 144 of ~250 issue slots),
-// so everything around the exponentials is squeezed:
-//   * K and V are gathered straight into LDS by LDS-DMA (global_load_lds_dwordx4: per-lane source
-//     address = the window's token row, lane-linear destination = row-major [144][32]); no VGPR
-//     round trip and no transposing stores: V is consumed through ds_read_b64_tr_b16.
-//   * the bias is the ACCUMULATOR INIT of the score MFMA: the host packs bias/scale (fp32, gathered
-//     through relative_position_index), the kernel loads it straight into the 36 accumulator
-//     registers and K·Qᵀ lands on top → no bias registers, no bias FMAs.  The next tile's bias (and
-//     its Q fragment) is requested as soon as the exponentials have freed those registers, under
-//     the P·V MFMAs and the output stores of the current tile.
-//   * softmax in base 2 on the raw accumulators: row max by v_max3_f32, then ONE packed FMA per
-//     score pair (acc·scale·log2e − max·scale·log2e) feeding v_exp_f32; row sums by packed adds;
-//     P is rounded to bf16 pairs as it is produced (18 registers).
-//   * the SW-MSA mask costs nothing on interior windows (wave-uniform branch); edge windows compare
-//     4 packed region ids per LDS word.
-//   96 registers → 5 waves per SIMD, six 3-wave blocks per CU.
+// bf16 MFMA kernel, v3 (used when the caller supplies the packed bias).  The kernel is VALU-issue- and
+// latency-bound (36 scores per lane and query tile: v_exp_f32 alone is 144 of ~250 issue slots), so everything
+// around the exponentials is squeezed:
+//   * K and V are gathered straight into LDS by LDS-DMA (global_load_lds_dwordx4: per-lane source address = the
+//     window's token row, lane-linear destination = row-major [144][32]); no VGPR round trip and no transposing
+//     stores: V is consumed through ds_read_b64_tr_b16.  The 16-byte chunks of a K row are XOR-swizzled with
+//     (row >> 2) & 3 (on the DMA source address and again on the fragment read): the ds_read_b128 of a K
+//     fragment then spreads a 16-lane service group over all 16 slots of the 256-byte bank row (it was 2-way).
+//   * the relative-position bias is the ACCUMULATOR INIT of the score MFMA and comes from LDS, not from HBM/L2:
+//     for a query (iy, ix) the four keys 16kt + 4fq .. +3 of an accumulator register quad lie in ONE window row
+//     (12 = 3 x 4), so their biases are four CONSECUTIVE entries of the (2ws-1)² table once its x axis is
+//     reversed: R[r][c'] = table[r][22 - c'], r = iy - jy + 11, c' = 11 - ix + jx.  With rows padded to 24 the
+//     quad starts at r·24 + 11 - ix + jx0, whose alignment mod 4 depends on the query only (jx0 ∈ {0,4,8}), so
+//     the host packs FOUR copies of R shifted by 0..3 floats (per head 9 KiB, pre-divided by `scale`) and one
+//     aligned ds_read_b128 per quad — from the copy (11 - ix) & 3 — lands the bias in the accumulator.  The
+//     dense [144,144] fp32 bias of v2 cost 83 KB of L2→CU traffic per (window, head) against 37 KB of q/k/v/o;
+//     this costs 9 KiB once per block (LDS-DMA) and one integer add per quad.
+//   * softmax in base 2 on the raw accumulators: row max by v_max3_f32, then ONE packed FMA per score pair
+//     (acc·scale·log2e − max·scale·log2e) feeding v_exp_f32; row sums by packed adds; P is rounded to bf16 pairs
+//     as it is produced (18 registers).
+//   * the SW-MSA mask costs nothing on interior windows (wave-uniform branch); edge windows compare 4 packed
+//     region ids per LDS word.
 // =================================================================================================
 typedef __attribute__((ext_vector_type(4))) short v4s_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int BS_COPY = 576;          // floats per shifted bias copy (23 rows x 24 + slack; 4 copies = 9 x 1 KiB)
 
 __device__ __forceinline__ float max3f(float a, float b, float c) {      // inputs are MFMA results: canonical
   float r;
@@ -320,9 +327,10 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {      // inpu
   return r;
 }
 
-__global__ __launch_bounds__(192, 5) void window_attention_bf16_v2_kernel(WinParams p) {
-  __shared__ __attribute__((aligned(16))) bf16_raw Ks[MAXN][HD];        // 9216 B
+__global__ __launch_bounds__(192, 4) void window_attention_bf16_v3_kernel(WinParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_raw Ks[MAXN][HD];        // 9216 B (chunk-swizzled rows)
   __shared__ __attribute__((aligned(16))) bf16_raw Vs[MAXN + 16][HD];   // 10240 B (rows 144..159 zero)
+  __shared__ __attribute__((aligned(16))) float Bs[4 * BS_COPY];        // 9216 B: 4 shifted copies of the bias table
   __shared__ int rows[MAXN];
   __shared__ __attribute__((aligned(4))) unsigned char rids[MAXN];
 
@@ -342,6 +350,15 @@ __global__ __launch_bounds__(192, 5) void window_attention_bf16_v2_kernel(WinPar
   const long ld = 3 * p.C;
   const bool masked = p.shift > 0 && (wy == p.nwin_side - 1 || wx == p.nwin_side - 1);
 
+  // bias copies of this head: 9 x 1 KiB of LDS-DMA, 3 per wave (independent of the token rows)
+  {
+    const float* bsrc = p.bias_shifted + (long)head * 4 * BS_COPY + lane * 4;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int blk = wave * 3 + i;
+      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc + blk * 256), (lptr_t)((char*)&Bs[0] + blk * 1024), 16, 0, 0);
+    }
+  }
   if (tid < MAXN) {
     long r; int rid;
     slot_to_token(p, b, wy, wx, tid, r, rid);
@@ -353,12 +370,13 @@ __global__ __launch_bounds__(192, 5) void window_attention_bf16_v2_kernel(WinPar
   // ---- LDS-DMA gather: instruction i covers window slots 16i .. 16i+15 (16 rows x 64 B = 1 KiB)
   {
     const int r_in = lane >> 2, ch = lane & 3;
+    const int chk = ch ^ ((r_in >> 2) & 3);                             // K: this LDS slot holds logical chunk chk
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int blk = wave * 3 + i;                                       // 0..8
-      const bf16_raw* src = qkv + (long)rows[blk * 16 + r_in] * ld + head * HD + ch * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + p.C), (lptr_t)((char*)&Ks[0][0] + blk * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + 2 * p.C), (lptr_t)((char*)&Vs[0][0] + blk * 1024), 16, 0, 0);
+      const bf16_raw* src = qkv + (long)rows[blk * 16 + r_in] * ld + head * HD;
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + p.C + chk * 8), (lptr_t)((char*)&Ks[0][0] + blk * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + 2 * p.C + ch * 8), (lptr_t)((char*)&Vs[0][0] + blk * 1024), 16, 0, 0);
     }
   }
   const int fr = lane & 15, fq = lane >> 4;
@@ -367,17 +385,22 @@ __global__ __launch_bounds__(192, 5) void window_attention_bf16_v2_kernel(WinPar
   bf16_raw* out = (bf16_raw*)p.out;
   // transposed-read addresses of V: lane (fr = 4q+p) of 16-lane group fq supplies row r0+q, cols 4p..4p+3
   const int voff = ((4 * fq + (fr >> 2)) * HD + 4 * (fr & 3)) * 2;
-  const float* bhead = p.bias_dense + (long)head * MAXN * MAXN + fq * 4;
-
-  // first tile: bias → accumulators and Q fragment (B operand of Sᵀ = K·Qᵀ: Q[query = fr][d = 8·fq ..])
-  f32x4_t sc[9];
-  bf16x8_t q;
-  {
-    const int qn = wave * 48 + fr;
+  // byte offset of key quad (kt, fq) inside a bias copy, relative to the query's origin: (-jy·24 + jx0)·4
+  int koffs[9];
 #pragma unroll
-    for (int kt = 0; kt < 9; ++kt) sc[kt] = *(const f32x4_t*)(bhead + (long)qn * MAXN + kt * 16);
-    q = *(const bf16x8_t*)(qkv + (long)rows[qn] * ld + head * HD + fq * 8);
+  for (int kt = 0; kt < 9; ++kt) {
+    const int key0 = kt * 16 + fq * 4;
+    const int jy = key0 / 12, jx0 = key0 - jy * 12;
+    koffs[kt] = (jx0 - jy * 24) * 4;
   }
+  auto bias_base = [&](int qn) -> int {                                  // byte address of the query's origin in ITS copy
+    const int iy = qn / 12, ix = qn - iy * 12;
+    const int s = (11 - ix) & 3;
+    return (s * BS_COPY + (iy + 11) * 24 + 11 - ix - s) * 4;
+  };
+
+  // first tile's Q fragment (B operand of Sᵀ = K·Qᵀ: Q[query = fr][d = 8·fq ..])
+  bf16x8_t q = *(const bf16x8_t*)(qkv + (long)rows[wave * 48 + fr] * ld + head * HD + fq * 8);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -385,12 +408,16 @@ __global__ __launch_bounds__(192, 5) void window_attention_bf16_v2_kernel(WinPar
   for (int qt = 0; qt < 3; ++qt) {
     const int qn = (wave * 3 + qt) * 16 + fr;
     const int orow = rows[qn];
-    // (the K / V fragment addresses are made opaque once per tile: otherwise hipcc hoists all 29
-    //  loop-invariant LDS reads out of the tile loop and parks 76 registers on them)
-    int koff = (fr * HD + fq * 8) * 2, vo = voff;
-    asm volatile("" : "+v"(koff), "+v"(vo));
+    // (the K / V / bias fragment addresses are made opaque once per tile: otherwise hipcc hoists the
+    //  loop-invariant LDS reads out of the tile loop and parks dozens of registers on them)
+    int koff = (fr * HD + ((fq ^ ((fr >> 2) & 3)) * 8)) * 2, vo = voff, bb = bias_base(qn);
+    asm volatile("" : "+v"(koff), "+v"(vo), "+v"(bb));
     const char* kbase = (const char*)&Ks[0][0] + koff;
     const char* vbase = (const char*)&Vs[0][0] + vo;
+    const char* bbase = (const char*)&Bs[0] + bb;
+    f32x4_t sc[9];
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) sc[kt] = *(const f32x4_t*)(bbase + koffs[kt]);
 #pragma unroll
     for (int kt = 0; kt < 9; ++kt) {
       const bf16x8_t kf = *(const bf16x8_t*)(kbase + kt * 16 * HD * 2);
@@ -437,13 +464,8 @@ __global__ __launch_bounds__(192, 5) void window_attention_bf16_v2_kernel(WinPar
         pk[kt][2 * h + 1] = (short)f32_to_bf16(e[1]);
       }
     }
-    // the accumulators are free: request the next tile's bias and Q under the P·V work below
-    if (qt < 2) {
-      const int qn1 = qn + 16;
-#pragma unroll
-      for (int kt = 0; kt < 9; ++kt) sc[kt] = *(const f32x4_t*)(bhead + (long)qn1 * MAXN + kt * 16);
-      q = *(const bf16x8_t*)(qkv + (long)rows[qn1] * ld + head * HD + fq * 8);
-    }
+    // request the next tile's Q under the P·V work below
+    if (qt < 2) q = *(const bf16x8_t*)(qkv + (long)rows[qn + 16] * ld + head * HD + fq * 8);
     float l = lsum[0] + lsum[1];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -479,7 +501,7 @@ __global__ __launch_bounds__(192, 5) void window_attention_bf16_v2_kernel(WinPar
 
 }  // namespace
 
-extern "C" int odic_window_attention(const void* qkv, const float* bias_table, const float* bias_dense_prescaled,
+extern "C" int odic_window_attention(const void* qkv, const float* bias_table, const float* bias_shifted_prescaled,
                                      void* out, int32_t B, int32_t res, int32_t C, int32_t heads, int32_t ws,
                                      int32_t shift, float scale, int32_t dtype, void* stream) {
   if (!qkv || !bias_table || !out) return ODIC_ENULL;
@@ -487,7 +509,7 @@ extern "C" int odic_window_attention(const void* qkv, const float* bias_table, c
     return ODIC_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return ODIC_EINVAL;
   WinParams p;
-  p.qkv = qkv; p.table = bias_table; p.bias_dense = bias_dense_prescaled; p.out = out; p.B = B; p.res = res; p.C = C; p.heads = heads;
+  p.qkv = qkv; p.table = bias_table; p.bias_shifted = bias_shifted_prescaled; p.out = out; p.B = B; p.res = res; p.C = C; p.heads = heads;
   p.ws = ws; p.shift = shift; p.nwin_side = res / ws; p.scale = scale;
   dim3 grid(B * p.nwin_side * p.nwin_side, heads), block(192);
   hipStream_t s = (hipStream_t)stream;
@@ -495,12 +517,12 @@ extern "C" int odic_window_attention(const void* qkv, const float* bias_table, c
     hipLaunchKernelGGL(window_attention_f32_kernel, grid, block, 0, s, p);
   } else if (dtype == ODIC_BF16) {
     if (ws != 12) return ODIC_EUNSUPPORTED;      // MFMA tiling is specialised for N = 144
-    if (bias_dense_prescaled && (long)B * res * res < 2147483647L && !(((uintptr_t)bias_dense_prescaled) & 15)) {
+    if (bias_shifted_prescaled && (long)B * res * res < 2147483647L && !(((uintptr_t)bias_shifted_prescaled) & 15)) {
       // (a persistent, double-buffered variant — one head x several windows per block — measured
       //  slower at every stage: with ~0.5 us of work per window a prefetch distance of one window does
       //  not cover the gather latency, and six independent 3-wave blocks per CU keep more bytes in flight)
       const int nwin = B * p.nwin_side * p.nwin_side;
-      hipLaunchKernelGGL(window_attention_bf16_v2_kernel, dim3(((nwin + 7) / 8) * 8 * heads), block, 0, s, p);
+      hipLaunchKernelGGL(window_attention_bf16_v3_kernel, dim3(((nwin + 7) / 8) * 8 * heads), block, 0, s, p);
     }
     else
       hipLaunchKernelGGL(window_attention_bf16_kernel, grid, block, 0, s, p);

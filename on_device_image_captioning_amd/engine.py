@@ -60,7 +60,7 @@ class SwinEngine:
                     n1w=f32(p + ".norm1.weight"), n1b=f32(p + ".norm1.bias"),
                     qkv_w=cw(p + ".attn.qkv.weight"), qkv_b=f32(p + ".attn.qkv.bias"),
                     table=f32(p + ".attn.relative_position_bias_table"),
-                    dense=(ops.dense_bias_prescaled(f32(p + ".attn.relative_position_bias_table"), g.stage_window(s),
+                    dense=(ops.shifted_bias_prescaled(f32(p + ".attn.relative_position_bias_table"), g.stage_window(s),
                                                     (g.stage_dim(s) // g.swin_num_heads[s]) ** -0.5)
                            if precision == "bf16" and g.stage_window(s) == 12 else None),
                     proj_w=cw(p + ".attn.proj.weight"), proj_b=f32(p + ".attn.proj.bias"),
@@ -92,7 +92,7 @@ class SwinEngine:
                 xn = ops.layernorm(x, w["n1w"], w["n1b"], out_dtype=cdt)
                 qkv = ops.gemm(xn, w["qkv_w"], w["qkv_b"])
                 att = ops.window_attention(qkv, w["table"], B, res, C_, heads, ws, w["shift"],
-                                           bias_dense_prescaled=w["dense"])
+                                           bias_shifted_prescaled=w["dense"])
                 ops.gemm(att, w["proj_w"], w["proj_b"], residual=x, out=x)
                 xn = ops.layernorm(x, w["n2w"], w["n2b"], out_dtype=cdt)
                 h = ops.gemm(xn, w["fc1_w"], w["fc1_b"], act=ops.ACT_GELU)

@@ -277,22 +277,28 @@ def patch_embed(img: torch.Tensor, w: torch.Tensor, b: torch.Tensor, gamma: torc
     return out
 
 
-def dense_bias_prescaled(bias_table: torch.Tensor, ws: int, scale: float) -> torch.Tensor:
-    """[heads, ws², ws²] fp32 = bias_table[relative_position_index] / scale — weight-pack-time plumbing for
-    odic_window_attention's fast path (the gather of reference swin_transformer_mod.py:196-198; the kernel
-    uses it as the accumulator init of q·kᵀ and multiplies by scale afterwards)."""
-    from .weights import relative_position_index
-    idx = relative_position_index(ws).to(bias_table.device)
-    n = ws * ws
-    dense = bias_table[idx.reshape(-1)].reshape(n, n, -1).permute(2, 0, 1)
-    return (dense.double() / scale).float().contiguous()
+def shifted_bias_prescaled(bias_table: torch.Tensor, ws: int, scale: float) -> torch.Tensor:
+    """[heads, 4, 576] fp32 — weight-pack-time plumbing for odic_window_attention's fast path (ws = 12): the
+    relative-position bias table (reference swin_transformer_mod.py:163-173,196-198) with its x axis reversed and
+    rows padded to 24, divided by `scale`, in four copies shifted by 0..3 floats, so that the biases of the four
+    consecutive keys of an MFMA accumulator quad are one aligned 16-byte LDS read (include/odic_hip.h)."""
+    if ws != 12:
+        raise RuntimeError("the packed bias layout is specialised for 12x12 windows")
+    heads = bias_table.shape[1]
+    t = (bias_table.double() / scale).float().view(23, 23, heads)           # [r, c, head]
+    R = torch.zeros(heads, 23 * 24 + 32, dtype=torch.float32, device=bias_table.device)
+    R[:, :23 * 24].view(heads, 23, 24)[:, :, :23] = t.flip(1).permute(2, 0, 1)
+    out = torch.zeros(heads, 4, 576, dtype=torch.float32, device=bias_table.device)
+    for s_ in range(4):
+        out[:, s_, :] = R[:, s_:s_ + 576]
+    return out.contiguous()
 
 
 def window_attention(qkv: torch.Tensor, bias_table: torch.Tensor, B: int, res: int, C_: int, heads: int, ws: int,
                      shift: int, *, scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
-                     bias_dense_prescaled: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """`bias_dense_prescaled` must have been packed with the same `scale` (default head_dim^-0.5)."""
-    _need_cuda(qkv, bias_table, out, bias_dense_prescaled)
+                     bias_shifted_prescaled: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`bias_shifted_prescaled` must have been packed with the same `scale` (default head_dim^-0.5)."""
+    _need_cuda(qkv, bias_table, out, bias_shifted_prescaled)
     if scale is None:
         scale = (C_ // heads) ** -0.5
     if out is None:
@@ -302,7 +308,7 @@ def window_attention(qkv: torch.Tensor, bias_table: torch.Tensor, B: int, res: i
     n = ws * ws
     with _timed("window_attention_bf16" if qkv.dtype == torch.bfloat16 else "window_attention_f32",
                 inst * 4.0 * n * n * 32, inst * 4.0 * n * 32 * qkv.element_size(), f"res{res}h{heads}"):
-        _hip.check(_hip.load().odic_window_attention(_p(qkv), _p(bias_table), _p(bias_dense_prescaled), _p(out), B, res, C_,
+        _hip.check(_hip.load().odic_window_attention(_p(qkv), _p(bias_table), _p(bias_shifted_prescaled), _p(out), B, res, C_,
                                                      heads, ws, shift,
                                                      scale, dtype_code(qkv.dtype), _stream()),
                    "odic_window_attention")

@@ -210,7 +210,7 @@ def test_window_attention(ops, res, heads, shift, dt):
     assert_close(got, want, 2e-5 if dt == torch.float32 else 1.2e-2, f"window_attention {dt}")
     if dt == torch.bfloat16:          # fast path: dense pre-gathered bias, LDS-DMA gathers, transposed LDS reads
         got2 = ops.window_attention(dev(qkv), dev(table), B, res, C, heads, ws, shift,
-                                    bias_dense_prescaled=ops.dense_bias_prescaled(dev(table), ws, 32 ** -0.5))
+                                    bias_shifted_prescaled=ops.shifted_bias_prescaled(dev(table), ws, 32 ** -0.5))
         assert_close(got2, want, 1.2e-2, "window_attention bf16 v2")
 
 

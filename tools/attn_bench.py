@@ -15,12 +15,12 @@ for res, heads in ((96, 6), (48, 12), (24, 24), (12, 48)):
     C = heads * 32
     qkv = torch.randn(B * res * res, 3 * C, device="cuda").bfloat16()
     table = (torch.randn(529, heads, device="cuda") * 0.1)
-    dense = ops.dense_bias_prescaled(table, 12, 32 ** -0.5)
+    dense = ops.shifted_bias_prescaled(table, 12, 32 ** -0.5)
     out = torch.empty(B * res * res, C, device="cuda", dtype=torch.bfloat16)
     inst = B * (res // 12) ** 2 * heads
     for shift in (0, 6 if res > 12 else 0):
         cells = []
-        for name, kw in (("v1", {}), ("v2", {"bias_dense_prescaled": dense})):
+        for name, kw in (("table", {}), ("packed", {"bias_shifted_prescaled": dense})):
             for _ in range(3):
                 ops.window_attention(qkv, table, B, res, C, heads, 12, shift, out=out, **kw)
             torch.cuda.synchronize()

@@ -15,8 +15,8 @@ C = heads * 32
 torch.manual_seed(0)
 qkv = torch.randn(B * res * res, 3 * C, device="cuda").bfloat16()
 table = torch.randn(529, heads, device="cuda") * 0.1
-dense = ops.dense_bias_prescaled(table, 12, 32 ** -0.5)
+dense = ops.shifted_bias_prescaled(table, 12, 32 ** -0.5)
 out = torch.empty(B * res * res, C, device="cuda", dtype=torch.bfloat16)
 for _ in range(5):
-    ops.window_attention(qkv, table, B, res, C, heads, 12, shift, out=out, bias_dense_prescaled=dense)
+    ops.window_attention(qkv, table, B, res, C, heads, 12, shift, out=out, bias_shifted_prescaled=dense)
 torch.cuda.synchronize()

@@ -29,7 +29,7 @@ def run_stage(x, s):
     for w in blocks:
         xn = ops.layernorm(x, w["n1w"], w["n1b"], out_dtype=swin.cdt)
         qkv = ops.gemm(xn, w["qkv_w"], w["qkv_b"])
-        att = ops.window_attention(qkv, w["table"], B, res, C_, heads, ws, w["shift"], bias_dense_prescaled=w["dense"])
+        att = ops.window_attention(qkv, w["table"], B, res, C_, heads, ws, w["shift"], bias_shifted_prescaled=w["dense"])
         ops.gemm(att, w["proj_w"], w["proj_b"], residual=x, out=x)
         xn = ops.layernorm(x, w["n2w"], w["n2b"], out_dtype=swin.cdt)
         h = ops.gemm(xn, w["fc1_w"], w["fc1_b"], act=ops.ACT_GELU)
