@@ -11,6 +11,7 @@ Workloads (`config.workload` in the output line):
   e2e16       BASELINE.json configs[2] (the headline metric): 16 synthetic 384x384 images per GPU per step →
               Swin-L → expansion encoder → beam-3 search, beam_max_seq_len 20, bf16 backbone/encoder.
   features48  configs[1]: features-only ExpansionNet_v2, 48 feature sets (144 x 1536) per step, beam 3, fp32.
+  fp8b64      configs[4]: the low-precision backbone mode (fp8 MFMA GEMMs, fp16 activations), 64 images per step.
   coco5k      configs[3] per-GPU shape: a step = 625 images (5000 / 8 ranks) in sub-batches of 16, beam 5,
               beam_max_seq_len 74, then ONE RCCL all_gather of the token ids — inside the timed step.
 Synthetic xavier weights never emit EOS, so every caption runs its full decode length.  Inputs are resident
@@ -59,6 +60,11 @@ WORKLOADS = {
         desc="COCO Karpathy-test 5k shape: 625 images per GPU (5000 over 8 ranks) in sub-batches of 16, beam 5, "
              "beam_max_seq_len 74, one RCCL all_gather of the token ids inside the step (BASELINE.json configs[3])",
         batch=16, beam=5, max_len=74, precision="bf16", steps=2, warmup=1, shard=625),
+    "fp8b64": dict(
+        desc="End_ExpansionNet_v2 end-to-end, Swin-L/384 backbone in the low-precision mode (fp8 e4m3 MFMA for the qkv / "
+             "fc1 / fc2 GEMMs with static scales, fp16 qkv / attention activations), batch 64 per GPU, beam 3, "
+             "beam_max_seq_len 20 (BASELINE.json configs[4])",
+        batch=64, beam=3, max_len=20, precision="fp8", steps=12, warmup=2),
 }
 
 
@@ -72,7 +78,7 @@ def parse():
     ap.add_argument("--beam", type=int, default=None)
     ap.add_argument("--max-len", type=int, default=None)
     ap.add_argument("--shard", type=int, default=None, help="coco5k: images per rank per step")
-    ap.add_argument("--precision", default=None, choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -255,6 +261,7 @@ def roofline_entry(name, d):
     sec = d["ms"] * 1e-3
     mfma = name.startswith("gemm") or name.startswith("swin_attention_block")
     if mfma:
+        # (the non-scaled fp8 MFMA issues at the bf16 rate, MI355X_MICROARCH.md § Matrix cores: priced against 2.5 PF)
         peak = PEAK["mfma_f32_tflops"] if name == "gemm_f32" else PEAK["mfma_bf16_tflops"]
         ach = d["flops"] / sec / 1e12
         e = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
@@ -421,12 +428,12 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "captions/sec end-to-end (Swin-L 384, beam=3) at 1/2/4/8 MI355X" if a.workload == "e2e16" else
-                      f"captions/sec ({a.workload})",
+            "metric": "captions/sec end-to-end (Swin-L 384, beam=3) at 1/2/4/8 MI355X" if a.workload in ("e2e16", "fp8b64")
+                      else f"captions/sec ({a.workload})",
             "value": round(per_step * world * a.steps / dt, 2), "unit": "captions/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.precision, "data": "synthetic",
+            "dtype": {"fp8": "fp8 (e4m3 GEMM operands) + fp16 activations"}.get(a.precision, a.precision), "data": "synthetic",
             "config": {"workload": WORKLOADS[a.workload]["desc"], "workload_key": a.workload,
                        "batch_per_gpu": a.batch, "beam": a.beam, "beam_max_seq_len": a.max_len,
                        "images_per_step_per_gpu": per_step,
@@ -438,7 +445,7 @@ def main():
                        "decode_group_batches": pipe.G,
                        "overlap": "encode graph of batch i+1 || beam-search step graphs of earlier batches, one HIP stream each"},
         }
-        if a.workload == "e2e16" and not a.no_parity:
+        if a.workload in ("e2e16", "fp8b64") and not a.no_parity:
             out["parity"] = parity_block(model, pipe, a, images, caps[:a.batch], g, device)
         if not a.no_roofline:
             fam = roofline_pass(pipe, images)

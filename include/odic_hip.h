@@ -16,7 +16,8 @@
  *   - return 0 on success, a negative ODIC_E* code on a rejected argument, or the positive
  *     hipError_t of a failed launch.  Nothing is printed.
  *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
- *   - dtype codes: ODIC_F32 = 0 (float), ODIC_BF16 = 1 (bfloat16, raw uint16 storage).
+ *   - dtype codes: ODIC_F32 = 0 (float), ODIC_BF16 = 1 (bfloat16, raw uint16 storage), ODIC_FP8 = 2 (OCP e4m3,
+ *     raw uint8), ODIC_F16 = 3 (IEEE half).
  */
 #ifndef ODIC_HIP_H
 #define ODIC_HIP_H
@@ -29,6 +30,8 @@ extern "C" {
 
 #define ODIC_F32 0
 #define ODIC_BF16 1
+#define ODIC_FP8 2     /* OCP e4m3 (e4m3fn), one byte per element: the low-precision backbone mode's GEMM operands */
+#define ODIC_F16 3     /* IEEE half: that mode's qkv / attention activations */
 
 #define ODIC_ACT_NONE 0
 #define ODIC_ACT_GELU 1    /* exact erf GELU (nn.GELU, swin_transformer_mod.py:87) */
@@ -40,7 +43,7 @@ extern "C" {
 #define ODIC_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ODIC_ABI_VERSION 9
+#define ODIC_ABI_VERSION 10
 int odic_abi_version(void);
 
 /* Human-readable build string ("gfx950 hipcc ..."), static storage. */
@@ -57,6 +60,10 @@ const char* odic_build_info(void);
  * End_ExpansionNet_v2.py:82,97,134,137.
  * in_dtype ODIC_BF16: MFMA 16x16x32 bf16, fp32 accumulate; needs K % 64 == 0, lda/ldw % 8 == 0,
  *   16-byte aligned A/W.   in_dtype ODIC_F32: MFMA 16x16x4 f32 (exact fp32 FMA chain), any M,N,K.
+ * in_dtype ODIC_FP8 / ODIC_F16 (low-precision backbone mode, BASELINE.json configs[4]): MFMA 16x16x32 fp8 / f16,
+ *   fp32 accumulate, out = cast(act(alpha·col_scale[n]·(A·Wᵀ) + bias)·out_scale) + residual with out_dtype in
+ *   {ODIC_F32, ODIC_F16, ODIC_FP8}; K a multiple of 128 (fp8) / 64 (f16); batch == 1.  The caller quantises: W per
+ *   output channel at pack time, A per tensor with a static scale — col_scale[n] is their product.
  * ------------------------------------------------------------------------------------------- */
 typedef struct odic_gemm_args {
   const void* A; const void* W; const float* bias; const float* residual; void* out;
@@ -84,12 +91,16 @@ typedef struct odic_gemm_args {
    * the kernel leaves them zero again, so ONE buffer serves every launch of a stream (launches of different
    * streams that may overlap need their own).  NULL otherwise. */
   int32_t* workspace;
+  /* fp8 / fp16 inputs only: per-output-column dequantisation factor (fp32 [N], NULL = 1) and the factor applied
+   * before the output cast (0 = 1; 1/scale of the consumer's fp8 operand). */
+  const float* col_scale; float out_scale;
 } odic_gemm_args;
 int odic_gemm(const odic_gemm_args* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps inside sqrt, biased variance — torch.nn.LayerNorm).
- *   x fp32 [M,C] (ldx) → out `out_dtype` [M,C] contiguous.   C % 4 == 0, C <= 8192.
+ *   x fp32 [M,C] (ldx) → out `out_dtype` [M,C] contiguous (ODIC_F32 / ODIC_BF16 / ODIC_FP8; an fp8 consumer's
+ *   quantisation scale is folded into gamma / beta by the caller).   C % 4 == 0, C <= 8192.
  * Replaces swin_transformer_mod.py:309,338 (norm1/norm2), :639 (final norm), layers.py:119,121,
  * 225,228,232 and the reduce norms End_ExpansionNet_v2.py:99,135.
  * ------------------------------------------------------------------------------------------- */

@@ -80,7 +80,7 @@ class End_ExpansionNet_v2(CaptioningModel):
             dv = self._device()
             sd = self.state_dict()
             self._eng_cache = (_engine.SwinEngine(sd, self.geometry, dv, self.precision),
-                               _engine.CaptionerEngine(sd, self.geometry, dv, self.encoder_precision or self.precision))
+                               _engine.CaptionerEngine(sd, self.geometry, dv, self.encoder_precision or ("bf16" if self.precision == "fp8" else self.precision)))
         return self._eng_cache
 
     def _captioner_engine(self):

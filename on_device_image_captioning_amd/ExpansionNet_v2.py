@@ -44,7 +44,7 @@ class ExpansionNet_v2(CaptioningModel):
     def _captioner_engine(self):
         if self._eng_cache is None:
             self._eng_cache = _engine.CaptionerEngine(self.state_dict(), self.geometry, self._device(),
-                                                          self.encoder_precision or self.precision)
+                                                          self.encoder_precision or ("bf16" if self.precision == "fp8" else self.precision))
         return self._eng_cache
 
     def _enc_lens(self, n, S, enc_input_num_pads):

@@ -12,9 +12,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libodic_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8, F16 = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _ERR = {-1: "ODIC_EINVAL (bad shape / alignment / enum)", -2: "ODIC_ENULL (required pointer is NULL)",
         -3: "ODIC_EUNSUPPORTED"}
@@ -30,7 +30,8 @@ class GemmArgs(C.Structure):
                 ("strideR", C.c_int64), ("strideC", C.c_int64),
                 ("alpha", C.c_float), ("act", C.c_int32), ("bias_axis", C.c_int32),
                 ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile_cfg", C.c_int32),
-                ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("workspace", C.c_void_p)]
+                ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("workspace", C.c_void_p),
+                ("col_scale", C.c_void_p), ("out_scale", C.c_float)]
 
 
 class BeamState(C.Structure):

@@ -46,12 +46,13 @@ class CaptioningModel(nn.Module):
             raise NotImplementedError("Subclass must assign the rank integer according to the GPU group")
 
     def set_precision(self, precision: str, encoder_precision: Optional[str] = None) -> "CaptioningModel":
-        """'fp32' (default; exact-fp32 MFMA, parity mode) or 'bf16' (backbone GEMMs + window
-        attention in bf16 with fp32 accumulation and an fp32 residual stream; expansion-encoder
-        products in bf16 too unless `encoder_precision='fp32'`).  The decoder is always fp32."""
-        for p in (precision, encoder_precision or precision):
-            if p not in ("fp32", "bf16"):
-                raise ValueError("precision must be 'fp32' or 'bf16'")
+        """'fp32' (default; exact-fp32 MFMA, parity mode), 'bf16' (backbone GEMMs + window attention in bf16 with
+        fp32 accumulation and an fp32 residual stream; expansion-encoder products in bf16 too unless
+        `encoder_precision='fp32'`) or 'fp8' (BASELINE.json configs[4]: Swin-block GEMMs qkv / fc1 / fc2 on the fp8
+        MFMA with statically calibrated scales, fp16 qkv / attention activations, everything else as 'bf16').
+        The decoder is always fp32."""
+        if precision not in ("fp32", "bf16", "fp8") or (encoder_precision or "bf16") not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32', 'bf16' or 'fp8' (encoder_precision 'fp32' or 'bf16')")
         if (precision, encoder_precision) != (self.precision, self.encoder_precision):
             self.precision, self.encoder_precision = precision, encoder_precision
             self._eng_cache = None

@@ -4,6 +4,7 @@
 
 int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream);
 int odic_gemm_f32_launch(const odic_gemm_args* a, hipStream_t stream);
+int odic_gemm_lowp_launch(const odic_gemm_args* a, hipStream_t stream);
 
 extern "C" int odic_abi_version(void) { return ODIC_ABI_VERSION; }
 
@@ -18,9 +19,10 @@ extern "C" int odic_gemm(const odic_gemm_args* a, void* stream) {
   if (a->residual && a->ldr < a->N) return ODIC_EINVAL;
   if (a->act < ODIC_ACT_NONE || a->act > ODIC_ACT_SIGMOID) return ODIC_EINVAL;
   if (a->bias_axis != 0 && a->bias_axis != 1) return ODIC_EINVAL;
-  if (a->out_dtype != ODIC_F32 && a->out_dtype != ODIC_BF16) return ODIC_EINVAL;
   if (a->batch > 65535) return ODIC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (a->in_dtype == ODIC_FP8 || a->in_dtype == ODIC_F16) return odic_gemm_lowp_launch(a, s);
+  if (a->out_dtype != ODIC_F32 && a->out_dtype != ODIC_BF16) return ODIC_EINVAL;
   if (a->in_dtype == ODIC_BF16) return odic_gemm_bf16_launch(a, s);
   if (a->in_dtype == ODIC_F32) return odic_gemm_f32_launch(a, s);
   return ODIC_EINVAL;

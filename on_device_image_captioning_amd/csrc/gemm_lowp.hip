@@ -1,0 +1,309 @@
+// fp8 (OCP e4m3) and fp16 NT GEMMs of the low-precision backbone mode (BASELINE.json configs[4]: "fp16 activations +
+// CDNA4 fp8 MFMA FFN / window GEMMs") for gfx950:
+//
+//     out = out_cast( act( alpha · col_scale[n] · (A·Wᵀ)[m][n] + bias ) · out_scale ) + residual
+//
+//   in_dtype ODIC_FP8   A [M,K], W [N,K] one byte per element (K contiguous); v_mfma_f32_16x16x32_fp8_fp8, fp32
+//                       accumulate.  Quantisation is the caller's: W per output channel (scale sw[n]) at pack time, A
+//                       per tensor with a static calibrated scale sa (written as fp8 by the producing kernel — the
+//                       LayerNorm with gamma/beta pre-divided by sa, or the fc1 epilogue through `out_scale`), so the
+//                       dequantisation is ONE per-column factor col_scale[n] = sa·sw[n] in the epilogue.
+//   in_dtype ODIC_F16   the attention-output projection (A = fp16 attention output, W fp16); v_mfma_f32_16x16x32_f16.
+//
+// Same structure as gemm_bf16.hip's one-block-per-tile kernel (LDS-DMA staging with the XOR chunk swizzle on the
+// source address and on the fragment read, counted vmcnt + raw barrier, operands swapped so a lane owns 8 adjacent
+// output columns of a row, W rows staged permuted, XCD-aware tile partition); what differs:
+//   * an LDS row is ROWB = 128 bytes = 128 fp8 K-elements (or 64 fp16): half the staging bytes per FLOP of bf16 —
+//     the generic tiles are L2→LDS-fill-bound, so this is where fp8 pays even at the bf16 MFMA rate
+//     of the non-scaled fp8 instruction;
+//   * a 16-byte ds_read_b128 fragment feeds TWO fp8 MFMAs (its low and high 8 bytes are the K-slots of two
+//     consecutive 32-deep steps; A and W use the same assignment, and a dot product does not care about K order).
+#include "odic_common.h"
+
+namespace {
+
+typedef unsigned char fp8_raw;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct Params {
+  const char* A; const char* W; const float* bias; const float* residual; const float* col_scale; void* out;
+  int M, N, K;                // K in ELEMENTS
+  long lda, ldw, ldr, ldc;    // elements
+  float alpha, out_scale; int act; int bias_axis;
+  int tiles_m, tiles_n, pm, pn;
+};
+
+__device__ __forceinline__ int swz128(int chunk, int row) { return chunk ^ (row & 7); }
+
+__device__ __forceinline__ int wperm(int r) {
+  return (r & ~31) + 8 * ((r & 15) >> 2) + 4 * ((r >> 4) & 1) + (r & 3);
+}
+
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) { return f32x4_to_fp8(a, b, c, d); }
+
+// EB = bytes per input element (1: fp8, 2: fp16).  OutT ∈ {float, f16_t, fp8_raw}.
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int EB, typename OutT>
+__global__ __launch_bounds__(64 * NWM * NWN) void gemm_lowp_nt_kernel(Params p) {
+  constexpr int NW = NWM * NWN;
+  constexpr int ROWB = 128;                    // bytes per LDS row
+  constexpr int BK = ROWB / EB;                // K elements per K-tile
+  constexpr int RPI = 1024 / ROWB;             // 8 rows per 1-KiB DMA instruction
+  constexpr int CPR = ROWB / 16;
+  constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
+  constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
+  constexpr int A_INSTR = BM / RPI / NW, W_INSTR = BN / RPI / NW;
+  static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "tile rows must split evenly over the waves");
+  constexpr int G = A_INSTR + W_INSTR;
+  static_assert(NI % 2 == 0, "the epilogue pairs MFMA column tiles");
+  constexpr int D = NSTAGE - 1;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / NWN, wn = wave % NWN;
+  ODIC_ENCODE_PRIO();
+
+  int tm, tn;
+  {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int xm = xcd / p.pn, xn = xcd - xm * p.pn;
+    const int r0 = xm * p.tiles_m / p.pm, r1 = (xm + 1) * p.tiles_m / p.pm;
+    const int c0 = xn * p.tiles_n / p.pn, c1 = (xn + 1) * p.tiles_n / p.pn;
+    const int w = c1 - c0;
+    if (idx >= (r1 - r0) * w) return;
+    const int lr = idx / w;
+    tm = r0 + lr; tn = c0 + (idx - lr * w);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int srow = lane / CPR;
+  const int schunk = swz128(lane % CPR, srow);
+  const char* a_src[A_INSTR];
+  const char* w_src[W_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int row = (i * NW + wave) * RPI + srow;
+    a_src[i] = p.A + ((long)min(m0 + row, p.M - 1) * p.lda) * EB + schunk * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < W_INSTR; ++i) {
+    const int row = (i * NW + wave) * RPI + srow;
+    w_src[i] = p.W + ((long)min(n0 + wperm(row), p.N - 1) * p.ldw) * EB + schunk * 16;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* la = lds + buf * STAGE;
+    char* lw = la + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (long)kt * ROWB), (lptr_t)(la + (i * NW + wave) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < W_INSTR; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (long)kt * ROWB), (lptr_t)(lw + (i * NW + wave) * 1024), 16, 0, 0);
+  };
+
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < D; ++t)
+    if (t < nk) stage(t, t);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = min(D - 1, nk - 1 - kt);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + D < nk) stage((kt + D) % NSTAGE, kt + D);
+
+    const int cur = kt % NSTAGE;
+    const char* la = lds + cur * STAGE + (wm * MI * 16 + frow) * ROWB;
+    const char* lw = lds + cur * STAGE + A_BYTES + (wn * NI * 16 + frow) * ROWB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {             // two 64-byte slabs per row: chunk kk*4 + fq
+      const int chunk = swz128(kk * 4 + fq, frow) << 4;
+      if constexpr (EB == 1) {
+        typedef __attribute__((ext_vector_type(2))) long l2_t;
+        l2_t af[MI], wf[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[mi] = *(const l2_t*)(la + mi * 16 * ROWB + chunk);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const l2_t*)(lw + ni * 16 * ROWB + chunk);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf[ni][h], af[mi][h], acc[mi][ni], 0, 0, 0);
+      } else {
+        f16x8_t af[MI], wf[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[mi] = *(const f16x8_t*)(la + mi * 16 * ROWB + chunk);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const f16x8_t*)(lw + ni * 16 * ROWB + chunk);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane (frow, fq) owns output row frow, 8 adjacent columns 32q + 8·fq .. +7 of each column pair
+  const float* bias = p.bias;
+  const float* resid = p.residual;
+  OutT* out = (OutT*)p.out;
+  const bool ld_ok = ((p.ldc & 7) == 0) && (!resid || (p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+#pragma unroll
+  for (int nq = 0; nq < NI / 2; ++nq) {
+    const int col = n0 + wn * NI * 16 + nq * 32 + fq * 8;
+    if (col >= p.N) continue;
+    float bc[8], cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bc[e] = (bias && !p.bias_axis && col + e < p.N) ? bias[col + e] : 0.f;
+      cs[e] = ((p.col_scale && col + e < p.N) ? p.col_scale[col + e] : 1.0f) * p.alpha;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int row = m0 + (wm * MI + mi) * 16 + frow;
+      if (row >= p.M) continue;
+      const float brow = (bias && p.bias_axis) ? bias[row] : 0.f;
+      f32x4_t v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4_t pre = acc[mi][2 * nq + h] * f32x4_t{cs[4 * h], cs[4 * h + 1], cs[4 * h + 2], cs[4 * h + 3]} +
+                      f32x4_t{bc[4 * h], bc[4 * h + 1], bc[4 * h + 2], bc[4 * h + 3]} + brow;
+        if (p.act == ODIC_ACT_GELU) {
+          pre = gelu_poly4(pre);
+        } else if (p.act != ODIC_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pre[e] = apply_act<true>(pre[e], p.act);
+        }
+        v[h] = pre * p.out_scale;
+      }
+      const bool full = ld_ok && col + 7 < p.N;
+      if (resid) {
+        if (full) {
+          const f32x4_t* rp = (const f32x4_t*)(resid + (long)row * p.ldr + col);
+          v[0] += rp[0]; v[1] += rp[1];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (col + e < p.N) v[e >> 2][e & 3] += resid[(long)row * p.ldr + col + e];
+        }
+      }
+      OutT* dst = out + (long)row * p.ldc + col;
+      if (full) {
+        if constexpr (sizeof(OutT) == 4) {
+          ((f32x4_t*)dst)[0] = v[0]; ((f32x4_t*)dst)[1] = v[1];
+        } else if constexpr (sizeof(OutT) == 2) {
+          f16x8_t pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { pk[e] = (_Float16)v[0][e]; pk[4 + e] = (_Float16)v[1][e]; }
+          *(f16x8_t*)dst = pk;
+        } else {
+          uint2 pk;
+          pk.x = pack_fp8x4(v[0][0], v[0][1], v[0][2], v[0][3]);
+          pk.y = pack_fp8x4(v[1][0], v[1][1], v[1][2], v[1][3]);
+          *(uint2*)dst = pk;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (col + e < p.N) {
+            const float x = v[e >> 2][e & 3];
+            if constexpr (sizeof(OutT) == 4) dst[e] = x;
+            else if constexpr (sizeof(OutT) == 2) dst[e] = (_Float16)x;
+            else dst[e] = (fp8_raw)(pack_fp8x4(x, 0.f, 0.f, 0.f) & 0xff);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int EB>
+int launch(Params& p, int out_dtype, hipStream_t stream) {
+  constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
+  constexpr int SHMEM = NSTAGE * (BM + BN) * 128;
+  p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+  int pn = 1;
+  while (pn < 8 && pn * 2 <= p.tiles_n && (double)p.N / pn * p.K * EB > 2.5 * 1024 * 1024) pn *= 2;
+  int pm = 8 / pn;
+  while (pm > p.tiles_m && pm > 1) { pm /= 2; pn *= 2; }
+  if (pn > p.tiles_n) { pn = 1; pm = 8; while (pm > p.tiles_m && pm > 1) pm /= 2; pn = 8 / pm; }
+  p.pm = pm; p.pn = pn;
+  int max_rect = 0;
+  for (int xm = 0; xm < pm; ++xm)
+    for (int xn = 0; xn < pn; ++xn) {
+      const int r = ((xm + 1) * p.tiles_m / pm - xm * p.tiles_m / pm) * ((xn + 1) * p.tiles_n / pn - xn * p.tiles_n / pn);
+      if (r > max_rect) max_rect = r;
+    }
+  dim3 grid(8 * max_rect), block(64 * NWM * NWN);
+  auto k32 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, EB, float>;
+  auto k16 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, EB, f16_t>;
+  auto k8 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, EB, fp8_raw>;
+  if (SHMEM > 64 * 1024) {
+    static bool done = false;       // code-object attribute; idempotent
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)k32, hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+      (void)hipFuncSetAttribute((const void*)k16, hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+      (void)hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+      done = true;
+    }
+  }
+  if (out_dtype == ODIC_F32) hipLaunchKernelGGL(k32, grid, block, SHMEM, stream, p);
+  else if (out_dtype == ODIC_F16) hipLaunchKernelGGL(k16, grid, block, SHMEM, stream, p);
+  else if (out_dtype == ODIC_FP8) hipLaunchKernelGGL(k8, grid, block, SHMEM, stream, p);
+  else return ODIC_EINVAL;
+  return odic_launch_status();
+}
+
+template <int EB>
+int dispatch(Params& p, const odic_gemm_args* a, hipStream_t stream) {
+  int cfg = a->tile_cfg;
+  if (cfg < 0) {
+    auto rounds = [&](int bm, int bn, int slots) {
+      const long t = (long)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn);
+      return (double)((t + slots - 1) / slots);
+    };
+    const double c0 = rounds(128, 64, 768) * 1.0, c1 = rounds(128, 128, 512) * 1.38, c2 = rounds(256, 128, 512) * 2.2;
+    cfg = (c0 <= c1 && c0 <= c2) ? 0 : (c1 <= c2 ? 1 : 2);
+  }
+  switch (cfg) {
+    case 0: return launch<2, 2, 4, 2, 2, EB>(p, a->out_dtype, stream);      // 128 x 64,  2 stages (48 KiB)
+    case 1: return launch<2, 2, 4, 4, 2, EB>(p, a->out_dtype, stream);      // 128 x 128, 2 stages (64 KiB)
+    case 2: return launch<4, 2, 4, 4, 2, EB>(p, a->out_dtype, stream);      // 256 x 128, 2 stages (96 KiB)
+    case 3: return launch<2, 2, 4, 4, 3, EB>(p, a->out_dtype, stream);      // 128 x 128, 3 stages (96 KiB)
+    case 4: return launch<4, 2, 4, 4, 3, EB>(p, a->out_dtype, stream);      // 256 x 128, 3 stages (144 KiB)
+    default: return ODIC_EINVAL;
+  }
+}
+
+}  // namespace
+
+int odic_gemm_lowp_launch(const odic_gemm_args* a, hipStream_t stream) {
+  const int eb = a->in_dtype == ODIC_FP8 ? 1 : 2;
+  const int bk = 128 / eb;
+  if (a->ln_colsum || a->batch != 1) return ODIC_EUNSUPPORTED;
+  if (a->K % bk != 0 || (a->lda * eb) % 16 != 0 || (a->ldw * eb) % 16 != 0) return ODIC_EINVAL;
+  if (((uintptr_t)a->A & 15) || ((uintptr_t)a->W & 15)) return ODIC_EINVAL;
+  if (a->out_dtype != ODIC_F32 && a->out_dtype != ODIC_F16 && a->out_dtype != ODIC_FP8) return ODIC_EINVAL;
+  if (a->out_dtype == ODIC_FP8 && a->residual) return ODIC_EINVAL;
+  Params p;
+  p.A = (const char*)a->A; p.W = (const char*)a->W; p.bias = a->bias; p.residual = a->residual;
+  p.col_scale = a->col_scale; p.out = a->out; p.M = a->M; p.N = a->N; p.K = a->K;
+  p.lda = a->lda; p.ldw = a->ldw; p.ldr = a->ldr; p.ldc = a->ldc;
+  p.alpha = a->alpha; p.out_scale = a->out_scale == 0.f ? 1.0f : a->out_scale; p.act = a->act; p.bias_axis = a->bias_axis;
+  return eb == 1 ? dispatch<1>(p, a, stream) : dispatch<2>(p, a, stream);
+}

@@ -85,10 +85,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       OutT* dst = out + (long)row * C + 4 * idx;
       if constexpr (sizeof(OutT) == 4) {
         *(float4*)dst = make_float4(o0, o1, o2, o3);
-      } else {
+      } else if constexpr (sizeof(OutT) == 2) {
         ushort4 pk;
         pk.x = f32_to_bf16(o0); pk.y = f32_to_bf16(o1); pk.z = f32_to_bf16(o2); pk.w = f32_to_bf16(o3);
         *(ushort4*)dst = pk;
+      } else {                                   // fp8 e4m3 (the consumer's scale is folded into gamma / beta)
+        *(unsigned*)dst = f32x4_to_fp8(o0, o1, o2, o3);
       }
     }
   }
@@ -247,6 +249,7 @@ extern "C" int odic_layernorm(const float* x, int64_t ldx, const float* gamma, c
   hipStream_t s = (hipStream_t)stream;
   if (out_dtype == ODIC_F32) return launch_ln<false, float>(x, ldx, gamma, beta, out, M, C, eps, 0, 0, s);
   if (out_dtype == ODIC_BF16) return launch_ln<false, bf16_raw>(x, ldx, gamma, beta, out, M, C, eps, 0, 0, s);
+  if (out_dtype == ODIC_FP8) return launch_ln<false, unsigned char>(x, ldx, gamma, beta, out, M, C, eps, 0, 0, s);
   return ODIC_EINVAL;
 }
 

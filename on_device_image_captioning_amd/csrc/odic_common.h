@@ -29,6 +29,16 @@ __device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
   return __builtin_bit_cast(bf16_raw, b);
 }
 
+// four floats → four OCP e4m3 bytes, saturating at ±448 (the converter alone returns NaN past the range)
+__device__ __forceinline__ unsigned f32x4_to_fp8(float a, float b, float c, float d) {
+  const float lim = 448.0f;
+  a = fminf(fmaxf(a, -lim), lim); b = fminf(fmaxf(b, -lim), lim);
+  c = fminf(fmaxf(c, -lim), lim); d = fminf(fmaxf(d, -lim), lim);
+  int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+  return (unsigned)v;
+}
+
 template <typename T> __device__ __forceinline__ float load_as_f32(const T* p);
 template <> __device__ __forceinline__ float load_as_f32<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_as_f32<bf16_raw>(const bf16_raw* p) { return bf16_to_f32(*p); }

@@ -327,6 +327,21 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {      // inpu
   return r;
 }
 
+// 16-bit element flavour of the fast kernel: bf16 (the default backbone mode) or IEEE fp16 (the low-precision mode's
+// activations, BASELINE.json configs[4]); same MFMA shape, same fragment layouts, same LDS image.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+template <bool F16> __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ unsigned short cvt16(float f) {
+  if constexpr (F16) { const _Float16 h = (_Float16)f; return __builtin_bit_cast(unsigned short, h); }
+  else return f32_to_bf16(f);
+}
+
+template <bool F16>
 __global__ __launch_bounds__(192, 4) void window_attention_bf16_v3_kernel(WinParams p) {
   __shared__ __attribute__((aligned(16))) bf16_raw Ks[MAXN][HD];        // 9216 B (chunk-swizzled rows)
   __shared__ __attribute__((aligned(16))) bf16_raw Vs[MAXN + 16][HD];   // 10240 B (rows 144..159 zero)
@@ -421,7 +436,7 @@ __global__ __launch_bounds__(192, 4) void window_attention_bf16_v3_kernel(WinPar
 #pragma unroll
     for (int kt = 0; kt < 9; ++kt) {
       const bf16x8_t kf = *(const bf16x8_t*)(kbase + kt * 16 * HD * 2);
-      sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, q, sc[kt], 0, 0, 0);
+      sc[kt] = mfma16<F16>(kf, q, sc[kt]);
     }
     if (masked) {
       const unsigned my = rids[qn];
@@ -460,8 +475,8 @@ __global__ __launch_bounds__(192, 4) void window_attention_bf16_v3_kernel(WinPar
         const f32x2_t a = f32x2_t{sc[kt][2 * h], sc[kt][2 * h + 1]} * s2 + c2;
         const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
         lsum += e;
-        pk[kt][2 * h] = (short)f32_to_bf16(e[0]);
-        pk[kt][2 * h + 1] = (short)f32_to_bf16(e[1]);
+        pk[kt][2 * h] = (short)cvt16<F16>(e[0]);
+        pk[kt][2 * h + 1] = (short)cvt16<F16>(e[1]);
       }
     }
     // request the next tile's Q under the P·V work below
@@ -485,15 +500,15 @@ __global__ __launch_bounds__(192, 4) void window_attention_bf16_v3_kernel(WinPar
         const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) v4s_t*)(vbase + (32 * s5 + 16) * HD * 2 + nt * 32));
         const bf16x8_t vf = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        oacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[nt], 0, 0, 0);
+        oacc[nt] = mfma16<F16>(vf, pf, oacc[nt]);
       }
     }
     bf16_raw* dst = out + (long)orow * p.C + head * HD + fq * 4;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       ushort4 o4;
-      o4.x = f32_to_bf16(oacc[nt][0] * inv_l); o4.y = f32_to_bf16(oacc[nt][1] * inv_l);
-      o4.z = f32_to_bf16(oacc[nt][2] * inv_l); o4.w = f32_to_bf16(oacc[nt][3] * inv_l);
+      o4.x = cvt16<F16>(oacc[nt][0] * inv_l); o4.y = cvt16<F16>(oacc[nt][1] * inv_l);
+      o4.z = cvt16<F16>(oacc[nt][2] * inv_l); o4.w = cvt16<F16>(oacc[nt][3] * inv_l);
       *(ushort4*)(dst + nt * 16) = o4;
     }
   }
@@ -522,10 +537,15 @@ extern "C" int odic_window_attention(const void* qkv, const float* bias_table, c
       //  slower at every stage: with ~0.5 us of work per window a prefetch distance of one window does
       //  not cover the gather latency, and six independent 3-wave blocks per CU keep more bytes in flight)
       const int nwin = B * p.nwin_side * p.nwin_side;
-      hipLaunchKernelGGL(window_attention_bf16_v3_kernel, dim3(((nwin + 7) / 8) * 8 * heads), block, 0, s, p);
+      hipLaunchKernelGGL(window_attention_bf16_v3_kernel<false>, dim3(((nwin + 7) / 8) * 8 * heads), block, 0, s, p);
     }
     else
       hipLaunchKernelGGL(window_attention_bf16_kernel, grid, block, 0, s, p);
+  } else if (dtype == ODIC_F16) {
+    if (ws != 12 || !bias_shifted_prescaled || (long)B * res * res >= 2147483647L || (((uintptr_t)bias_shifted_prescaled) & 15))
+      return ODIC_EUNSUPPORTED;                  // fp16 activations: packed-bias MFMA kernel only
+    const int nwin = B * p.nwin_side * p.nwin_side;
+    hipLaunchKernelGGL(window_attention_bf16_v3_kernel<true>, dim3(((nwin + 7) / 8) * 8 * heads), block, 0, s, p);
   } else {
     return ODIC_EINVAL;
   }

@@ -26,7 +26,10 @@ from . import _hip, ops
 from .weights import Geometry
 
 SD = Dict[str, torch.Tensor]
-_CDT = {"fp32": torch.float32, "bf16": torch.bfloat16}
+# precision → dtype of the backbone's bf16-class activations / weights.  "fp8" (BASELINE.json configs[4]) keeps that
+# at bf16 for the patch-merge reductions and the backbone output, and runs the Swin blocks with fp8 GEMM operands
+# (qkv, fc1, fc2: 11/12 of the block FLOPs) and fp16 qkv / attention activations (proj on the fp16 MFMA).
+_CDT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp8": torch.bfloat16}
 
 
 def _dev(t: torch.Tensor, device, dtype=None) -> torch.Tensor:
@@ -40,11 +43,13 @@ def _dev(t: torch.Tensor, device, dtype=None) -> torch.Tensor:
 # Swin backbone  
 # =================================================================================================
 class SwinEngine:
-    def __init__(self, sd: SD, g: Geometry, device, precision: str = "fp32"):
+    def __init__(self, sd: SD, g: Geometry, device, precision: str = "fp32", calibration_images=None):
         if precision not in _CDT:
             raise ValueError(f"precision must be one of {list(_CDT)}")
         self.g, self.device, self.precision = g, device, precision
         self.cdt = _CDT[precision]
+        fp8 = precision == "fp8"
+        fast_attn = precision in ("bf16", "fp8")
         P = "swin_transf"
         f32 = lambda k: _dev(sd[k], device, torch.float32)          # noqa: E731
         cw = lambda k: _dev(sd[k], device, torch.float32).to(self.cdt).contiguous()   # noqa: E731
@@ -61,8 +66,8 @@ class SwinEngine:
                     qkv_w=cw(p + ".attn.qkv.weight"), qkv_b=f32(p + ".attn.qkv.bias"),
                     table=f32(p + ".attn.relative_position_bias_table"),
                     dense=(ops.shifted_bias_prescaled(f32(p + ".attn.relative_position_bias_table"), g.stage_window(s),
-                                                    (g.stage_dim(s) // g.swin_num_heads[s]) ** -0.5)
-                           if precision == "bf16" and g.stage_window(s) == 12 else None),
+                                                      (g.stage_dim(s) // g.swin_num_heads[s]) ** -0.5)
+                           if fast_attn and g.stage_window(s) == 12 else None),
                     proj_w=cw(p + ".attn.proj.weight"), proj_b=f32(p + ".attn.proj.bias"),
                     n2w=f32(p + ".norm2.weight"), n2b=f32(p + ".norm2.bias"),
                     fc1_w=cw(p + ".mlp.fc1.weight"), fc1_b=f32(p + ".mlp.fc1.bias"),
@@ -74,14 +79,54 @@ class SwinEngine:
                 down = dict(nw=f32(p + ".norm.weight"), nb=f32(p + ".norm.bias"), red_w=cw(p + ".reduction.weight"))
             self.stages.append((blocks, down))
         self.fn_w, self.fn_b = f32(f"{P}.norm.weight"), f32(f"{P}.norm.bias")
+        self.fp8_ready = False
+        if fp8:
+            self._pack_fp8(sd, calibration_images)
 
-    def forward(self, img: torch.Tensor, taps: Optional[dict] = None, out_dtype=torch.float32) -> torch.Tensor:
+    # ------------------------------------------------------------------------------------------ fp8 mode
+    def _pack_fp8(self, sd: SD, calibration_images) -> None:
+        """Static quantisation of the Swin blocks: per-output-channel fp8 weights for qkv / fc1 / fc2, fp16 weights
+        for proj, and per-tensor activation scales (LayerNorm outputs, GELU hidden) calibrated on one bf16 pass over
+        `calibration_images` (default: two synthetic images) — amax x 1.25 mapped to the e4m3 maximum.  The activation
+        scale of a LayerNorm output is folded into its gamma / beta, the product (activation scale x weight channel
+        scale) is the consuming GEMM's `col_scale`, the GELU hidden is written as fp8 through `out_scale`."""
+        from .weights import synth_images
+        g, dv = self.g, self.device
+        if any(g.stage_window(s) != 12 or g.stage_dim(s) % 128 for s in range(len(g.swin_depths))):
+            raise RuntimeError("fp8 mode needs 12x12 windows and stage widths that are multiples of 128 (Swin-L)")
+        img = calibration_images if calibration_images is not None else synth_images(2, g, seed=7)
+        amax = {}
+        self.forward(img.to(dv, torch.float32), _amax=amax)                 # bf16 pass recording the operand ranges
+        P = "swin_transf"
+        margin = 1.25
+        for s, (blocks, _) in enumerate(self.stages):
+            for b, w in enumerate(blocks):
+                p = f"{P}.layers.{s}.blocks.{b}"
+                s1 = margin * amax[(s, b, "ln1")] / ops.FP8_MAX
+                s2 = margin * amax[(s, b, "ln2")] / ops.FP8_MAX
+                sh = margin * amax[(s, b, "hid")] / ops.FP8_MAX
+                f32 = lambda k: _dev(sd[k], dv, torch.float32)      # noqa: E731
+                q_qkv, sw_qkv = ops.quantize_fp8_per_channel(f32(p + ".attn.qkv.weight"))
+                q_fc1, sw_fc1 = ops.quantize_fp8_per_channel(f32(p + ".mlp.fc1.weight"))
+                q_fc2, sw_fc2 = ops.quantize_fp8_per_channel(f32(p + ".mlp.fc2.weight"))
+                w.update(dict(
+                    n1w8=(w["n1w"] / s1).contiguous(), n1b8=(w["n1b"] / s1).contiguous(),
+                    n2w8=(w["n2w"] / s2).contiguous(), n2b8=(w["n2b"] / s2).contiguous(),
+                    qkv_w8=q_qkv, qkv_cs=(sw_qkv * s1).contiguous(),
+                    fc1_w8=q_fc1, fc1_cs=(sw_fc1 * s2).contiguous(), hid_inv=1.0 / sh,
+                    fc2_w8=q_fc2, fc2_cs=(sw_fc2 * sh).contiguous(),
+                    proj_w16=f32(p + ".attn.proj.weight").to(torch.float16).contiguous()))
+        self.fp8_ready = True
+
+    def forward(self, img: torch.Tensor, taps: Optional[dict] = None, out_dtype=torch.float32,
+                _amax: Optional[dict] = None) -> torch.Tensor:
         """img fp32 [B,3,H,W] on the engine's device → features [B, res_last², C_last] (`out_dtype`)."""
         g, cdt = self.g, self.cdt
         if img.dtype != torch.float32 or not img.is_cuda:
             raise RuntimeError("SwinEngine.forward wants an fp32 CUDA image batch")
         img = img.contiguous()
         B = img.shape[0]
+        fp8 = self.fp8_ready and _amax is None
         x = ops.patch_embed(img, self.pe_w, self.pe_b, self.pe_g, self.pe_beta, g.swin_patch_size)
         if taps is not None:
             taps["patch_embed"] = x.clone()
@@ -89,14 +134,32 @@ class SwinEngine:
             res, C_, heads, ws = g.stage_res(s), g.stage_dim(s), g.swin_num_heads[s], g.stage_window(s)
             x = x.view(B * res * res, C_)
             for bi, w in enumerate(blocks):
-                xn = ops.layernorm(x, w["n1w"], w["n1b"], out_dtype=cdt)
-                qkv = ops.gemm(xn, w["qkv_w"], w["qkv_b"])
-                att = ops.window_attention(qkv, w["table"], B, res, C_, heads, ws, w["shift"],
-                                           bias_shifted_prescaled=w["dense"])
-                ops.gemm(att, w["proj_w"], w["proj_b"], residual=x, out=x)
-                xn = ops.layernorm(x, w["n2w"], w["n2b"], out_dtype=cdt)
-                h = ops.gemm(xn, w["fc1_w"], w["fc1_b"], act=ops.ACT_GELU)
-                ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x)
+                if fp8:
+                    # LN → fp8 | qkv: fp8 MFMA → fp16 | attention fp16 | proj: fp16 MFMA + residual
+                    xn = ops.layernorm(x, w["n1w8"], w["n1b8"], out_dtype=ops.FP8_DTYPE)
+                    qkv = ops.gemm(xn, w["qkv_w8"], w["qkv_b"], col_scale=w["qkv_cs"], out_dtype=torch.float16)
+                    att = ops.window_attention(qkv, w["table"], B, res, C_, heads, ws, w["shift"],
+                                               bias_shifted_prescaled=w["dense"])
+                    ops.gemm(att, w["proj_w16"], w["proj_b"], residual=x, out=x)
+                    # LN → fp8 | fc1: fp8 MFMA + GELU → fp8 | fc2: fp8 MFMA + residual
+                    xn = ops.layernorm(x, w["n2w8"], w["n2b8"], out_dtype=ops.FP8_DTYPE)
+                    h = ops.gemm(xn, w["fc1_w8"], w["fc1_b"], act=ops.ACT_GELU, col_scale=w["fc1_cs"],
+                                 out_scale=w["hid_inv"], out_dtype=ops.FP8_DTYPE)
+                    ops.gemm(h, w["fc2_w8"], w["fc2_b"], residual=x, out=x, col_scale=w["fc2_cs"])
+                else:
+                    xn = ops.layernorm(x, w["n1w"], w["n1b"], out_dtype=cdt)
+                    if _amax is not None:
+                        _amax[(s, bi, "ln1")] = float(xn.float().abs().max())
+                    qkv = ops.gemm(xn, w["qkv_w"], w["qkv_b"])
+                    att = ops.window_attention(qkv, w["table"], B, res, C_, heads, ws, w["shift"],
+                                               bias_shifted_prescaled=w["dense"])
+                    ops.gemm(att, w["proj_w"], w["proj_b"], residual=x, out=x)
+                    xn = ops.layernorm(x, w["n2w"], w["n2b"], out_dtype=cdt)
+                    h = ops.gemm(xn, w["fc1_w"], w["fc1_b"], act=ops.ACT_GELU)
+                    if _amax is not None:
+                        _amax[(s, bi, "ln2")] = float(xn.float().abs().max())
+                        _amax[(s, bi, "hid")] = float(h.float().abs().max())
+                    ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x)
                 if taps is not None:
                     taps[f"s{s}b{bi}"] = x.view(B, res * res, C_).clone()
             if down is not None:

@@ -13,9 +13,11 @@ from typing import Optional, Sequence
 import torch
 
 from . import _hip
-from ._hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F32  # noqa: F401  (re-exported)
+from ._hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F16, F32, FP8  # noqa: F401  (re-exported)
 
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+FP8_DTYPE = torch.float8_e4m3fn          # OCP e4m3: the fp8 format of gfx950's MFMA
+FP8_MAX = 448.0
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16, FP8_DTYPE: FP8}
 
 
 def _stream() -> C.c_void_p:
@@ -157,12 +159,15 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
          M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None,
          lda: Optional[int] = None, ldw: Optional[int] = None, ldr: Optional[int] = None,
          ldc: Optional[int] = None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideBias: int = 0,
-         strideR: int = 0, strideC: int = 0, ln_fold: Optional[tuple] = None, tile_cfg: int = -1) -> torch.Tensor:
+         strideR: int = 0, strideC: int = 0, ln_fold: Optional[tuple] = None, tile_cfg: int = -1,
+         col_scale: Optional[torch.Tensor] = None, out_scale: float = 1.0) -> torch.Tensor:
     """out = act(alpha·A·Wᵀ + bias) + residual.  With no explicit dims, A is [..., K] (flattened to
     [M,K]) and W is [N,K], both contiguous.  Explicit dims / leading dimensions / batch strides allow
     strided sub-matrices (elements).  ln_fold = (colsum, eps): W and bias come from fold_layernorm() and
-    the rows of A are LayerNorm-ed inside the product (fp32 skinny-M path only)."""
-    _need_cuda(A, W, bias, residual, out)
+    the rows of A are LayerNorm-ed inside the product (fp32 skinny-M path only).  fp8 / fp16 operands (the
+    low-precision backbone mode): `col_scale` fp32 [N] multiplies column n of A·Wᵀ (activation scale x weight channel
+    scale) and `out_scale` the result before an fp8 / fp16 output cast."""
+    _need_cuda(A, W, bias, residual, out, col_scale)
     if A.dtype != W.dtype:
         raise RuntimeError("A and W must share a dtype")
     if M is None:
@@ -190,7 +195,8 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
     a = _hip.GemmArgs(_p(A), _p(W), _p(bias), _p(residual), _p(out), M, N, K, lda, ldw, ldr or 0, ldc, batch,
                       strideA, strideW, strideBias, strideR, strideC, alpha, act, bias_axis,
                       dtype_code(A.dtype), dtype_code(out.dtype), tile_cfg,
-                      _p(ln_fold[0]) if ln_fold else None, float(ln_fold[1]) if ln_fold else 0.0, None)
+                      _p(ln_fold[0]) if ln_fold else None, float(ln_fold[1]) if ln_fold else 0.0, None,
+                      _p(col_scale), float(out_scale))
     if A.dtype == torch.bfloat16:
         if batch == 1:
             a.workspace = _gemm_workspace(A.device).data_ptr()
@@ -205,7 +211,8 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
     nbytes = batch * ((M * K if strideA or batch == 1 else M * K / batch) * isz +
                       (N * K if strideW or batch == 1 else N * K / batch) * isz + M * N * osz +
                       (M * N * 4 if residual is not None else 0))
-    with _timed("gemm_bf16" if A.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * batch, nbytes,
+    fam = {torch.bfloat16: "gemm_bf16", torch.float16: "gemm_f16", FP8_DTYPE: "gemm_fp8"}.get(A.dtype, "gemm_f32")
+    with _timed(fam, 2.0 * M * N * K * batch, nbytes,
                 f"{M}x{N}x{K}" + (f"x{batch}" if batch > 1 else "")):
         _hip.check(_hip.load().odic_gemm(C.byref(a), _stream()), "odic_gemm")
     return out
@@ -306,7 +313,7 @@ def window_attention(qkv: torch.Tensor, bias_table: torch.Tensor, B: int, res: i
     # algorithmic work per (window, head): QKᵀ + PV = 4·N²·hd FLOP; q,k,v in + o out = 4·N·hd elements
     inst = B * (res // ws) ** 2 * heads
     n = ws * ws
-    with _timed("window_attention_bf16" if qkv.dtype == torch.bfloat16 else "window_attention_f32",
+    with _timed("window_attention_bf16" if qkv.dtype in (torch.bfloat16, torch.float16) else "window_attention_f32",
                 inst * 4.0 * n * n * 32, inst * 4.0 * n * 32 * qkv.element_size(), f"res{res}h{heads}"):
         _hip.check(_hip.load().odic_window_attention(_p(qkv), _p(bias_table), _p(bias_shifted_prescaled), _p(out), B, res, C_,
                                                      heads, ws, shift,
@@ -445,3 +452,12 @@ def beam_finalize_best(state: "_hip.BeamState", order, score, out_tok, out_len, 
 def beam_reset(state: "_hip.BeamState", n_img, beams, T, sos_idx) -> None:
     with _timed("beam_reset", 0.0, n_img * beams * 28.0):
         _hip.check(_hip.load().odic_beam_reset(C.byref(state), n_img, beams, T, sos_idx, _stream()), "odic_beam_reset")
+
+
+def quantize_fp8_per_channel(w: torch.Tensor):
+    """Weight-pack-time plumbing of the fp8 mode: W fp32 [N, K] → (fp8 e4m3 [N, K], scale fp32 [N]) with
+    W ≈ fp8·scale[:, None], scale = max|row| / 448 (the whole e4m3 range per output channel)."""
+    w = w.detach().float()
+    scale = (w.abs().amax(dim=1).clamp_min(1e-12) / FP8_MAX)
+    q = (w / scale[:, None]).clamp(-FP8_MAX, FP8_MAX).cpu().to(FP8_DTYPE)        # host cast: exact OCP round-to-nearest-even
+    return q.to(w.device).contiguous(), scale.contiguous()

@@ -559,3 +559,66 @@ def test_logsoftmax_sample_draws_follow_the_distribution(ops):
     lg = dev(rnd(4, 10000, seed=8))
     ops.logsoftmax_sample(lg, 10000, full, 10000, val[:4], idx[:4], 4, 10000, k, 5, None)
     assert_close(full, torch.log_softmax(lg.double().cpu(), -1), 2e-6, "logp_out")
+
+
+# ------------------------------------------------------------------------------------------ fp8 / fp16 GEMM (configs[4])
+def _to_fp8(t):
+    return t.clamp(-448, 448).to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+def test_gemm_fp8_identity_and_random(ops, cfg):
+    """odic_gemm with fp8 (OCP e4m3) operands: exact on integer data with A = I and an ASYMMETRIC W (layout check of
+    the 16x16x32 fp8 MFMA fragments, the two-MFMAs-per-16-byte-read K assignment, the permuted W rows), then random
+    data against fp64 of the same fp8 values with every epilogue feature (per-column scale, bias, GELU, out_scale,
+    residual) and the three output types."""
+    n = 256
+    eye = _to_fp8(torch.eye(n))
+    Wt = _to_fp8(((torch.arange(n)[:, None] * 3 + torch.arange(n)[None, :] * 5) % 17 - 8).float())
+    got = ops.gemm(dev(eye), dev(Wt), out_dtype=torch.float32, tile_cfg=cfg)
+    assert torch.equal(got.cpu(), Wt.float().T.contiguous())
+    for (M, N, K) in ((300, 328, 256), (517, 264, 384), (2304, 768, 1024)):
+        A, Wq = _to_fp8(rnd(M, K, seed=1, scale=2.0)), _to_fp8(rnd(N, K, seed=2, scale=3.0))
+        cs, b, r = rnd(N, seed=3).abs() * 0.01 + 0.005, rnd(N, seed=4), rnd(M, N, seed=5)
+        lin = (A.double() @ Wq.double().T) * cs.double() + b.double()
+        got = ops.gemm(dev(A), dev(Wq), dev(b), dev(r), col_scale=dev(cs), out_dtype=torch.float32, tile_cfg=cfg)
+        assert_close(got, lin + r.double(), 2e-5, f"fp8 cfg{cfg} {M}x{N}x{K} → f32")
+        got16 = ops.gemm(dev(A), dev(Wq), dev(b), col_scale=dev(cs), out_dtype=torch.float16, tile_cfg=cfg)
+        assert_close(got16, lin, 1e-3, "fp8 → f16")
+        got8 = ops.gemm(dev(A), dev(Wq), dev(b), act=1, col_scale=dev(cs), out_scale=7.0, out_dtype=torch.float8_e4m3fn,
+                        tile_cfg=cfg)
+        want8 = torch.nn.functional.gelu(lin) * 7.0
+        err = (got8.float().cpu().double() - want8).abs()
+        assert float((err - want8.abs() * 2 ** -4).max()) <= 2 ** -9 + 1e-6, "fp8 → fp8: half an e4m3 ulp (3 mantissa bits)"
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+def test_gemm_f16(ops, cfg):
+    for (M, N, K) in ((256, 256, 64), (517, 264, 320)):
+        A, Wt = rnd(M, K, seed=1).half(), rnd(N, K, seed=2, scale=0.05).half()
+        b, r = rnd(N, seed=3), rnd(M, N, seed=4)
+        want = (A.double() @ Wt.double().T) + b.double() + r.double()
+        got = ops.gemm(dev(A), dev(Wt), dev(b), dev(r), out_dtype=torch.float32, tile_cfg=cfg)
+        assert_close(got, want, 2e-5, f"f16 cfg{cfg} {M}x{N}x{K}")
+
+
+def test_layernorm_fp8_output(ops):
+    x, g, b = rnd(300, 768, seed=1, scale=2.0), 1 + rnd(768, seed=2, scale=0.1), rnd(768, seed=3, scale=0.05)
+    s_ = 0.02                                                    # consumer's quantisation scale, folded into gamma / beta
+    got = ops.layernorm(dev(x), dev(g / s_), dev(b / s_), out_dtype=torch.float8_e4m3fn)
+    want = torch.nn.functional.layer_norm(x.double(), (768,), g.double(), b.double()) / s_
+    err = (got.float().cpu().double() - want.clamp(-448, 448)).abs()
+    assert float((err - want.abs().clamp(max=448) * 2 ** -4).max()) <= 2 ** -9 + 1e-6
+
+
+@pytest.mark.parametrize("res,heads,shift", [(48, 6, 6), (24, 12, 0), (12, 48, 0)])
+def test_window_attention_fp16(ops, res, heads, shift):
+    B, ws = 2, 12
+    C = heads * 32
+    qkv = rnd(B * res * res, 3 * C, seed=res + shift, scale=1.5).half()
+    table = rnd(529, heads, seed=9, scale=0.5)
+    want = _win_ref(qkv.float(), table, B, res, C, heads, ws, shift)
+    got = ops.window_attention(dev(qkv), dev(table), B, res, C, heads, ws, shift,
+                               bias_shifted_prescaled=ops.shifted_bias_prescaled(dev(table), ws, 32 ** -0.5))
+    assert got.dtype == torch.float16
+    assert_close(got, want, 2.5e-3, "window_attention fp16")
