@@ -62,7 +62,7 @@ const char* odic_build_info(void);
  *   16-byte aligned A/W.   in_dtype ODIC_F32: MFMA 16x16x4 f32 (exact fp32 FMA chain), any M,N,K.
  * in_dtype ODIC_FP8 / ODIC_F16 (low-precision backbone mode, BASELINE.json configs[4]): MFMA 16x16x32 fp8 / f16,
  *   fp32 accumulate, out = cast(act(alpha·col_scale[n]·(A·Wᵀ) + bias)·out_scale) + residual with out_dtype in
- *   {ODIC_F32, ODIC_F16, ODIC_FP8}; K a multiple of 128 (fp8) / 64 (f16); batch == 1.  The caller quantises: W per
+ *   {ODIC_F32, ODIC_F16, ODIC_FP8}; K a multiple of 64 (fp8) / 32 (f16); batch == 1.  The caller quantises: W per
  *   output channel at pack time, A per tensor with a static scale — col_scale[n] is their product.
  * ------------------------------------------------------------------------------------------- */
 typedef struct odic_gemm_args {

@@ -36,7 +36,12 @@ struct Params {
   int tiles_m, tiles_n, pm, pn;
 };
 
-__device__ __forceinline__ int swz128(int chunk, int row) { return chunk ^ (row & 7); }
+// 16-byte-chunk swizzle inside an LDS row (as gemm_bf16.hip): 128-byte rows: chunk ^ (row & 7); 64-byte rows (4 rows share
+// a 256-byte bank row): chunk ^ f((row >> 2) & 3), f = {0, 2, 3, 1}.
+template <int ROWB> __device__ __forceinline__ int swz(int chunk, int row) {
+  if constexpr (ROWB == 128) return chunk ^ (row & 7);
+  else return chunk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3);
+}
 
 __device__ __forceinline__ int wperm(int r) {
   return (r & ~31) + 8 * ((r & 15) >> 2) + 4 * ((r >> 4) & 1) + (r & 3);
@@ -45,12 +50,11 @@ __device__ __forceinline__ int wperm(int r) {
 __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) { return f32x4_to_fp8(a, b, c, d); }
 
 // EB = bytes per input element (1: fp8, 2: fp16).  OutT ∈ {float, f16_t, fp8_raw}.
-template <int NWM, int NWN, int MI, int NI, int NSTAGE, int EB, typename OutT>
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int ROWB, int EB, typename OutT>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_lowp_nt_kernel(Params p) {
   constexpr int NW = NWM * NWN;
-  constexpr int ROWB = 128;                    // bytes per LDS row
   constexpr int BK = ROWB / EB;                // K elements per K-tile
-  constexpr int RPI = 1024 / ROWB;             // 8 rows per 1-KiB DMA instruction
+  constexpr int RPI = 1024 / ROWB;             // rows per 1-KiB DMA instruction
   constexpr int CPR = ROWB / 16;
   constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_lowp_nt_kernel(Params p) 
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int srow = lane / CPR;
-  const int schunk = swz128(lane % CPR, srow);
+  const int schunk = swz<ROWB>(lane % CPR, srow);
   const char* a_src[A_INSTR];
   const char* w_src[W_INSTR];
 #pragma unroll
@@ -127,8 +131,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_lowp_nt_kernel(Params p) 
     const char* la = lds + cur * STAGE + (wm * MI * 16 + frow) * ROWB;
     const char* lw = lds + cur * STAGE + A_BYTES + (wn * NI * 16 + frow) * ROWB;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {             // two 64-byte slabs per row: chunk kk*4 + fq
-      const int chunk = swz128(kk * 4 + fq, frow) << 4;
+    for (int kk = 0; kk < ROWB / 64; ++kk) {     // 64-byte slabs of a row: chunk kk*4 + fq
+      const int chunk = swz<ROWB>(kk * 4 + fq, frow) << 4;
       if constexpr (EB == 1) {
         typedef __attribute__((ext_vector_type(2))) long l2_t;
         l2_t af[MI], wf[NI];
@@ -232,10 +236,10 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_lowp_nt_kernel(Params p) 
   }
 }
 
-template <int NWM, int NWN, int MI, int NI, int NSTAGE, int EB>
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int ROWB, int EB>
 int launch(Params& p, int out_dtype, hipStream_t stream) {
   constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
-  constexpr int SHMEM = NSTAGE * (BM + BN) * 128;
+  constexpr int SHMEM = NSTAGE * (BM + BN) * ROWB;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
   int pn = 1;
   while (pn < 8 && pn * 2 <= p.tiles_n && (double)p.N / pn * p.K * EB > 2.5 * 1024 * 1024) pn *= 2;
@@ -250,9 +254,9 @@ int launch(Params& p, int out_dtype, hipStream_t stream) {
       if (r > max_rect) max_rect = r;
     }
   dim3 grid(8 * max_rect), block(64 * NWM * NWN);
-  auto k32 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, EB, float>;
-  auto k16 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, EB, f16_t>;
-  auto k8 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, EB, fp8_raw>;
+  auto k32 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, ROWB, EB, float>;
+  auto k16 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, ROWB, EB, f16_t>;
+  auto k8 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, ROWB, EB, fp8_raw>;
   if (SHMEM > 64 * 1024) {
     static bool done = false;       // code-object attribute; idempotent
     if (!done) {
@@ -280,12 +284,21 @@ int dispatch(Params& p, const odic_gemm_args* a, hipStream_t stream) {
     const double c0 = rounds(128, 64, 768) * 1.0, c1 = rounds(128, 128, 512) * 1.38, c2 = rounds(256, 128, 512) * 2.2;
     cfg = (c0 <= c1 && c0 <= c2) ? 0 : (c1 <= c2 ? 1 : 2);
   }
+  if ((a->K * EB) % 128 == 0) {
+    switch (cfg) {
+      case 0: return launch<2, 2, 4, 2, 2, 128, EB>(p, a->out_dtype, stream);      // 128 x 64,  2 stages (48 KiB)
+      case 1: return launch<2, 2, 4, 4, 2, 128, EB>(p, a->out_dtype, stream);      // 128 x 128, 2 stages (64 KiB)
+      case 2: return launch<4, 2, 4, 4, 2, 128, EB>(p, a->out_dtype, stream);      // 256 x 128, 2 stages (96 KiB)
+      case 3: return launch<2, 2, 4, 4, 3, 128, EB>(p, a->out_dtype, stream);      // 128 x 128, 3 stages (96 KiB)
+      case 4: return launch<4, 2, 4, 4, 3, 128, EB>(p, a->out_dtype, stream);      // 256 x 128, 3 stages (144 KiB)
+      default: return ODIC_EINVAL;
+    }
+  }
+  // K·EB a multiple of 64 bytes only (Swin-L stage 0: K = 192 fp8): 64-byte LDS rows, three stages
   switch (cfg) {
-    case 0: return launch<2, 2, 4, 2, 2, EB>(p, a->out_dtype, stream);      // 128 x 64,  2 stages (48 KiB)
-    case 1: return launch<2, 2, 4, 4, 2, EB>(p, a->out_dtype, stream);      // 128 x 128, 2 stages (64 KiB)
-    case 2: return launch<4, 2, 4, 4, 2, EB>(p, a->out_dtype, stream);      // 256 x 128, 2 stages (96 KiB)
-    case 3: return launch<2, 2, 4, 4, 3, EB>(p, a->out_dtype, stream);      // 128 x 128, 3 stages (96 KiB)
-    case 4: return launch<4, 2, 4, 4, 3, EB>(p, a->out_dtype, stream);      // 256 x 128, 3 stages (144 KiB)
+    case 0: return launch<2, 2, 4, 2, 3, 64, EB>(p, a->out_dtype, stream);         // 128 x 64  (36 KiB)
+    case 1: case 3: return launch<2, 2, 4, 4, 3, 64, EB>(p, a->out_dtype, stream); // 128 x 128 (48 KiB)
+    case 2: case 4: return launch<4, 2, 4, 4, 3, 64, EB>(p, a->out_dtype, stream); // 256 x 128 (72 KiB)
     default: return ODIC_EINVAL;
   }
 }
@@ -294,7 +307,7 @@ int dispatch(Params& p, const odic_gemm_args* a, hipStream_t stream) {
 
 int odic_gemm_lowp_launch(const odic_gemm_args* a, hipStream_t stream) {
   const int eb = a->in_dtype == ODIC_FP8 ? 1 : 2;
-  const int bk = 128 / eb;
+  const int bk = 64 / eb;                       // K granularity: one 64-byte LDS row
   if (a->ln_colsum || a->batch != 1) return ODIC_EUNSUPPORTED;
   if (a->K % bk != 0 || (a->lda * eb) % 16 != 0 || (a->ldw * eb) % 16 != 0) return ODIC_EINVAL;
   if (((uintptr_t)a->A & 15) || ((uintptr_t)a->W & 15)) return ODIC_EINVAL;

@@ -92,8 +92,8 @@ class SwinEngine:
         scale) is the consuming GEMM's `col_scale`, the GELU hidden is written as fp8 through `out_scale`."""
         from .weights import synth_images
         g, dv = self.g, self.device
-        if any(g.stage_window(s) != 12 or g.stage_dim(s) % 128 for s in range(len(g.swin_depths))):
-            raise RuntimeError("fp8 mode needs 12x12 windows and stage widths that are multiples of 128 (Swin-L)")
+        if any(g.stage_window(s) != 12 or g.stage_dim(s) % 64 for s in range(len(g.swin_depths))):
+            raise RuntimeError("fp8 mode needs 12x12 windows and stage widths that are multiples of 64 (Swin-L: 192·2^s)")
         img = calibration_images if calibration_images is not None else synth_images(2, g, seed=7)
         amax = {}
         self.forward(img.to(dv, torch.float32), _amax=amax)                 # bf16 pass recording the operand ranges

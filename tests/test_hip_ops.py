@@ -577,7 +577,7 @@ def test_gemm_fp8_identity_and_random(ops, cfg):
     Wt = _to_fp8(((torch.arange(n)[:, None] * 3 + torch.arange(n)[None, :] * 5) % 17 - 8).float())
     got = ops.gemm(dev(eye), dev(Wt), out_dtype=torch.float32, tile_cfg=cfg)
     assert torch.equal(got.cpu(), Wt.float().T.contiguous())
-    for (M, N, K) in ((300, 328, 256), (517, 264, 384), (2304, 768, 1024)):
+    for (M, N, K) in ((300, 328, 256), (517, 264, 384), (2304, 768, 1024), (1000, 576, 192)):   # K = 192: 64-byte rows
         A, Wq = _to_fp8(rnd(M, K, seed=1, scale=2.0)), _to_fp8(rnd(N, K, seed=2, scale=3.0))
         cs, b, r = rnd(N, seed=3).abs() * 0.01 + 0.005, rnd(N, seed=4), rnd(M, N, seed=5)
         lin = (A.double() @ Wq.double().T) * cs.double() + b.double()
