@@ -126,14 +126,17 @@ class autotune:
         return False
 
 
-def _tune_gemm(args: "_hip.GemmArgs", key, out: torch.Tensor) -> int:
+_LOWP_CANDIDATES = (0, 1, 2, 3, 4)          # gemm_lowp.hip tile configurations (fp8 / fp16 operands)
+
+
+def _tune_gemm(args: "_hip.GemmArgs", key, out: torch.Tensor, candidates=None) -> int:
     lib = _hip.load()
     scratch = torch.empty_like(out)
     real_out = args.out
     args.out = scratch.data_ptr()
     best, best_ms = -1, float("inf")
     try:
-        for cfg in _TILE_CANDIDATES:
+        for cfg in (candidates or _TILE_CANDIDATES):
             args.tile_cfg = cfg
             if lib.odic_gemm(C.byref(args), _stream()) != 0:
                 continue
@@ -197,14 +200,14 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
                       dtype_code(A.dtype), dtype_code(out.dtype), tile_cfg,
                       _p(ln_fold[0]) if ln_fold else None, float(ln_fold[1]) if ln_fold else 0.0, None,
                       _p(col_scale), float(out_scale))
-    if A.dtype == torch.bfloat16:
-        if batch == 1:
+    if A.dtype in (torch.bfloat16, torch.float16, FP8_DTYPE):
+        if batch == 1 and A.dtype == torch.bfloat16:
             a.workspace = _gemm_workspace(A.device).data_ptr()
-        key = (M, N, K, batch, out.dtype, act, residual is not None)
+        key = (A.dtype, M, N, K, batch, out.dtype, act, residual is not None)
         cfg = _TILE_CHOICE.get(key) if tile_cfg < 0 else tile_cfg
         if cfg is None and _TUNING and _PROFILE is None and ldc == N and batch == 1 \
                 and not torch.cuda.is_current_stream_capturing():
-            cfg = _tune_gemm(a, key, out)
+            cfg = _tune_gemm(a, key, out, None if A.dtype == torch.bfloat16 else _LOWP_CANDIDATES)
         if cfg is not None:
             a.tile_cfg = cfg
     isz, osz = A.element_size(), out.element_size()

@@ -761,14 +761,15 @@ def test_tiny64_fp8_backbone_close_to_oracle():
 
 
 def test_full_fp8_margin_aware_parity_and_pipeline():
-    """configs[4] at the Swin-L geometry: teacher-forced log-probs on the reference's greedy captions within 0.5 nat,
-    arg-max identical wherever the reference's top-1/top-2 margin exceeds twice the local error, and the hipGraph
-    pipeline (batch 16) returns exactly the un-pipelined fp8-mode captions."""
+    """configs[4] at the Swin-L geometry (xavier checkpoint, realistic logit scale): backbone features within 1.5e-1
+    of the fp32 reference's (e4m3 operands: 2^-4 relative rounding, ten times bf16's), teacher-forced log-probs on the
+    reference's greedy captions within 1 nat, arg-max identical wherever the reference's top-1/top-2 margin exceeds
+    twice the local error, and the hipGraph pipeline (batch 16) returns exactly the un-pipelined fp8-mode captions."""
     from oracle import expansionnet_ref as R
     from on_device_image_captioning_amd.pipeline import CaptionPipeline
     g = W.FULL
-    sd = cached_state_dict("FULL", "eos")
-    store = np.load(os.path.join(GOLDEN, "full_eos.npz"))
+    sd = cached_state_dict("FULL", "xavier")
+    store = np.load(os.path.join(GOLDEN, "full_xavier.npz"))
     img = W.synth_images(2, g)
     ref_tok = unpad(store["beam1_T20.tokens"])
     T = max(len(r[0]) for r in ref_tok)
@@ -780,7 +781,7 @@ def test_full_fp8_margin_aware_parity_and_pipeline():
     feats_ref = R.swin_forward(sd, g, img)
     mem_ref = R.encoder_forward(sd, g, feats_ref, [0, 0])
     lp_ref = R.decoder_forward(sd, g, mem_ref, [0, 0], dec, pads, True)
-    m = build_model("FULL", "eos", "fp8")
+    m = build_model("FULL", "xavier", "fp8")
     swin, cap = m._engines()
     feats = swin.forward(img.to(DEV))
     rel = (feats.cpu() - feats_ref).abs().max().item() / feats_ref.abs().max().item()
@@ -797,10 +798,10 @@ def test_full_fp8_margin_aware_parity_and_pipeline():
                 checked += 1
                 flips += int(lp[b, t].argmax() != lp_ref[b, t].argmax())
     _diag("full_fp8", dict(swin_rel_err=rel, max_logprob_err=errs, margin_checked=checked, flips=flips))
-    assert rel < 1.5e-1 and max(errs) < 0.5 and flips == 0
+    assert rel < 1.5e-1 and max(errs) < 1.0 and flips == 0, (rel, errs, flips, checked)
     batches = _bench_batches(2, g)
     pipe = CaptionPipeline(m, 16, 3, 20, SOS, EOS)
     got = _drain(pipe, batches)
     want = [c for b in batches for c in _direct(m, b)]
-    build_model("FULL", "eos", "fp32")
+    build_model("FULL", "xavier", "fp32")
     assert got == want
