@@ -582,7 +582,7 @@ def test_gemm_fp8_identity_and_random(ops, cfg):
         cs, b, r = rnd(N, seed=3).abs() * 0.01 + 0.005, rnd(N, seed=4), rnd(M, N, seed=5)
         lin = (A.double() @ Wq.double().T) * cs.double() + b.double()
         got = ops.gemm(dev(A), dev(Wq), dev(b), dev(r), col_scale=dev(cs), out_dtype=torch.float32, tile_cfg=cfg)
-        assert_close(got, lin + r.double(), 2e-5, f"fp8 cfg{cfg} {M}x{N}x{K} → f32")
+        assert_close(got, lin + r.double(), 1e-4, f"fp8 cfg{cfg} {M}x{N}x{K} → f32")     # fp32 accumulation inside the fp8 MFMA
         got16 = ops.gemm(dev(A), dev(Wq), dev(b), col_scale=dev(cs), out_dtype=torch.float16, tile_cfg=cfg)
         assert_close(got16, lin, 1e-3, "fp8 → f16")
         got8 = ops.gemm(dev(A), dev(Wq), dev(b), act=1, col_scale=dev(cs), out_scale=7.0, out_dtype=torch.float8_e4m3fn,
