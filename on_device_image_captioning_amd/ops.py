@@ -99,6 +99,24 @@ def dtype_code(dt: torch.dtype) -> int:
 # fastest; later calls (including the captured ones) reuse the choice.
 _TILE_CHOICE: dict = {}
 _TUNING = False
+# ODIC_TILE_CACHE=<file>: tile choices are loaded from / appended to a JSON file, so a later process (a profiler
+# pass that must not contain tuning launches, a server restart) starts from the measured choices
+_TILE_CACHE_FILE = os.environ.get("ODIC_TILE_CACHE")
+
+
+def _cache_key(key) -> str:
+    return "|".join(str(k) for k in key)
+
+
+def _load_tile_cache() -> dict:
+    if _TILE_CACHE_FILE and os.path.exists(_TILE_CACHE_FILE):
+        import json
+        with open(_TILE_CACHE_FILE) as f:
+            return json.load(f)
+    return {}
+
+
+_TILE_CACHE: dict = _load_tile_cache()
 _TILE_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_TILE_CANDIDATES", "0,1,7,10").split(","))
 
 # persistent tile configurations (16 + c) draw tiles from atomic counters in a 16-int workspace that is zero at
@@ -153,6 +171,11 @@ def _tune_gemm(args: "_hip.GemmArgs", key, out: torch.Tensor, candidates=None) -
     finally:
         args.out = real_out
     _TILE_CHOICE[key] = best
+    if _TILE_CACHE_FILE:
+        import json
+        _TILE_CACHE[_cache_key(key)] = best
+        with open(_TILE_CACHE_FILE, "w") as f:
+            json.dump(_TILE_CACHE, f, indent=0)
     return best
 
 
@@ -205,6 +228,10 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
             a.workspace = _gemm_workspace(A.device).data_ptr()
         key = (A.dtype, M, N, K, batch, out.dtype, act, residual is not None)
         cfg = _TILE_CHOICE.get(key) if tile_cfg < 0 else tile_cfg
+        if cfg is None and tile_cfg < 0 and _TILE_CACHE:
+            cfg = _TILE_CACHE.get(_cache_key(key))
+            if cfg is not None:
+                _TILE_CHOICE[key] = cfg
         if cfg is None and _TUNING and _PROFILE is None and ldc == N and batch == 1 \
                 and not torch.cuda.is_current_stream_capturing():
             cfg = _tune_gemm(a, key, out, None if A.dtype == torch.bfloat16 else _LOWP_CANDIDATES)

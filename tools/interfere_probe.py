@@ -14,7 +14,7 @@ from on_device_image_captioning_amd.pipeline import CaptionPipeline
 
 torch.set_grad_enabled(False)
 dev = torch.device("cuda", 0)
-model, sd, g = bench.build_model(dev, "bf16")
+model, sd, g = bench.build_model(dev, "bf16", "e2e16")
 pipe = CaptionPipeline(model, 16, 3, 20, 79, 77, decode_lanes=1)
 st = pipe.states[0]
 cap = pipe.cap

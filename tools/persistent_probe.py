@@ -21,7 +21,7 @@ lib = ctypes.CDLL(so)
 lib.spin_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 torch.set_grad_enabled(False)
 dev = torch.device("cuda", 0)
-model, sd, g = bench.build_model(dev, "bf16")
+model, sd, g = bench.build_model(dev, "bf16", "e2e16")
 pipe = CaptionPipeline(model, 16, 3, 20, 79, 77, decode_lanes=2)
 sink = torch.zeros(1, device=dev)
 side = torch.cuda.Stream()

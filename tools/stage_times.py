@@ -15,7 +15,7 @@ from on_device_image_captioning_amd.pipeline import CaptionPipeline
 torch.set_grad_enabled(False)
 dev = torch.device("cuda", 0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-model, sd, g = bench.build_model(dev, "bf16")
+model, sd, g = bench.build_model(dev, "bf16", "e2e16")
 D = int(os.environ.get("ODIC_LANES", "2"))
 G = int(os.environ.get("ODIC_GROUP", "1"))
 E = int(os.environ.get("ODIC_ENC_LANES", "1"))
