@@ -43,7 +43,7 @@ extern "C" {
 #define ODIC_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ODIC_ABI_VERSION 10
+#define ODIC_ABI_VERSION 11
 int odic_abi_version(void);
 
 /* Human-readable build string ("gfx950 hipcc ..."), static storage. */
@@ -94,6 +94,16 @@ typedef struct odic_gemm_args {
   /* fp8 / fp16 inputs only: per-output-column dequantisation factor (fp32 [N], NULL = 1) and the factor applied
    * before the output cast (0 = 1; 1/scale of the consumer's fp8 operand). */
   const float* col_scale; float out_scale;
+  /* LayerNorm folded across two bf16 products (one-block-per-tile tile configurations 0..11, batch == 1) — removes
+   * the separate norm1 / norm2 launches of a Swin block (swin_transformer_mod.py:309,338) and their fp32 re-read
+   * of the residual stream:
+   *   producer (out_dtype ODIC_F32, e.g. the proj / fc2 product with the residual added): out16 (bf16 [M,N], ld16)
+   *     receives the rounded copy of `out`; stats_out (fp32 [M, N/32, 2]) receives, per row and 32-column group, the
+   *     mean and the centred sum of squares of those bf16 values.  N % 32 == 0.
+   *   consumer (A = that bf16 copy): ln_stats = the producer's stats_out (K/32 groups per row), ln_colsum and the
+   *     packed W / bias as for the fp32 form above; out = act(rstd·(alpha·A·W'ᵀ − mean·ln_colsum) + bias') + residual. */
+  void* out16; int64_t ld16; float* stats_out;
+  const float* ln_stats;
 } odic_gemm_args;
 int odic_gemm(const odic_gemm_args* args, void* stream);
 

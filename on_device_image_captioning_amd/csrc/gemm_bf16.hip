@@ -40,6 +40,13 @@ struct Params {
   int tiles_m, tiles_n;
   int pm, pn;          // XCD partition of the tile grid, pm * pn == 8
   int* ws;             // persistent kernels: 8 per-partition tile counters + 1 exit counter (all zero at launch)
+  // LayerNorm folded across two products (one-block-per-tile kernel only):
+  //   producer (fp32 out): also writes the bf16 copy of its output rows and, per row and 32-column group, the
+  //                        mean and centred sum of squares of those bf16 values;
+  //   consumer: A is that bf16 copy; row moments are combined from the K/32 groups and the epilogue computes
+  //             rstd·(A·W'ᵀ − mean·colsum) + bias' = LayerNorm(A)·Wᵀ + bias (W', colsum, bias' packed by the caller).
+  bf16_raw* out16; long ld16; float* stats_out;
+  const float* ln_stats; const float* ln_colsum; float ln_eps;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -140,6 +147,23 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
   for (int t = 0; t < D; ++t)
     if (t < nk) stage(t, t);
 
+  // folded LayerNorm, consumer side: (mean, rstd) of this tile's BM rows of A from the per-32-column-group
+  // moments its producer left (Chan's combination of equal-sized groups) → LDS tail, read in the epilogue
+  float2* s_stat = (float2*)(lds + NSTAGE * STAGE);
+  if (p.ln_stats) {
+    const int ng = p.K >> 5;
+    for (int r = tid; r < BM; r += 64 * NW) {
+      const int row = min(m0 + r, p.M - 1);
+      const float2* st = (const float2*)p.ln_stats + (long)row * ng;
+      float msum = 0.f;
+      for (int g = 0; g < ng; ++g) msum += st[g].x;
+      const float mean = msum / (float)ng;
+      float m2 = 0.f;
+      for (int g = 0; g < ng; ++g) { const float2 t = st[g]; const float d = t.x - mean; m2 += t.y + 32.0f * d * d; }
+      s_stat[r] = make_float2(mean, rsqrtf(m2 / (float)p.K + p.ln_eps));
+    }
+  }
+
   for (int kt = 0; kt < nk; ++kt) {
     const int ahead = min(D - 1, nk - 1 - kt);
     if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
@@ -179,18 +203,27 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
   for (int nq = 0; nq < NI / 2; ++nq) {
     const int col = n0 + wn * NI * 16 + nq * 32 + fq * 8;
     if (col >= p.N) continue;
-    float bc[8];
+    float bc[8], cs[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bc[e] = (bias && !p.bias_axis && col + e < p.N) ? bias[col + e] : 0.f;
+    for (int e = 0; e < 8; ++e) {
+      bc[e] = (bias && !p.bias_axis && col + e < p.N) ? bias[col + e] : 0.f;
+      cs[e] = (p.ln_stats && col + e < p.N) ? p.ln_colsum[col + e] : 0.f;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      const int row = m0 + (wm * MI + mi) * 16 + frow;
+      const int rloc = (wm * MI + mi) * 16 + frow;
+      const int row = m0 + rloc;
       if (row >= p.M) continue;
       const float brow = (bias && p.bias_axis) ? bias[row] : 0.f;
+      float2 mr = make_float2(0.f, 1.f);
+      if (p.ln_stats) mr = s_stat[rloc];
       f32x4_t v[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        f32x4_t pre = acc[mi][2 * nq + h] * p.alpha + f32x4_t{bc[4 * h], bc[4 * h + 1], bc[4 * h + 2], bc[4 * h + 3]} + brow;
+        f32x4_t lin = acc[mi][2 * nq + h] * p.alpha;
+        if (p.ln_stats)
+          lin = (lin - f32x4_t{cs[4 * h], cs[4 * h + 1], cs[4 * h + 2], cs[4 * h + 3]} * mr.x) * mr.y;
+        f32x4_t pre = lin + f32x4_t{bc[4 * h], bc[4 * h + 1], bc[4 * h + 2], bc[4 * h + 3]} + brow;
         if (p.act == ODIC_ACT_GELU) {
           pre = gelu_poly4(pre);
         } else if (p.act != ODIC_ACT_NONE) {
@@ -207,6 +240,29 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
         OutT* dst = out + (long)row * p.ldc + col;
         if constexpr (sizeof(OutT) == 4) {
           ((f32x4_t*)dst)[0] = v[0]; ((f32x4_t*)dst)[1] = v[1];
+          if (p.out16) {
+            // folded LayerNorm, producer side: the bf16 copy the next product reads as its A operand, and the
+            // moments of THOSE bf16 values over this row's 32-column group (the 4 fq lanes of a row hold it)
+            bf16x8_t pk;
+            float a8[8], sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const bf16_raw hb = f32_to_bf16(v[e >> 2][e & 3]);
+              pk[e] = (short)hb;
+              a8[e] = bf16_to_f32(hb);
+              sum += a8[e];
+            }
+            *(bf16x8_t*)(p.out16 + (long)row * p.ld16 + col) = pk;
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float gmean = sum * (1.0f / 32.0f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = a8[e] - gmean; m2 += d * d; }
+            m2 += __shfl_xor(m2, 16, 64);
+            m2 += __shfl_xor(m2, 32, 64);
+            if (fq == 0) ((float2*)p.stats_out)[(long)row * (p.N >> 5) + (col >> 5)] = make_float2(gmean, m2);
+          }
         } else {
           bf16x8_t pk;
 #pragma unroll
@@ -733,7 +789,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256sq_kernel(Params p) {
 template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK = 64>
 int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
   constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
-  constexpr int SHMEM = NSTAGE * (BM + BN) * BK * 2;
+  constexpr int SHMEM = NSTAGE * (BM + BN) * BK * 2 + BM * 8;          // + (mean, rstd) per row of the tile
   if (p.K % BK != 0) return ODIC_EINVAL;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
   // XCD partition: fewest column parts whose W sub-panel (N/pn x K bf16) fits ~2.5 MiB of the 4 MiB L2
@@ -848,7 +904,7 @@ int launch_256sq(Params& p, int out_dtype, int batch, hipStream_t stream) {
 }  // namespace
 
 int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
-  if (a->ln_colsum) return ODIC_EUNSUPPORTED;
+  if (a->ln_colsum && !a->ln_stats) return ODIC_EUNSUPPORTED;          // (the in-kernel moments form is fp32 skinny only)
   if (a->K % 64 != 0 || a->lda % 8 != 0 || a->ldw % 8 != 0) return ODIC_EINVAL;
   if (((uintptr_t)a->A & 15) || ((uintptr_t)a->W & 15)) return ODIC_EINVAL;
   if ((a->strideA % 8) || (a->strideW % 8)) return ODIC_EINVAL;
@@ -860,6 +916,16 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
   p.strideR = a->strideR; p.strideC = a->strideC;
   p.alpha = a->alpha; p.act = a->act; p.bias_axis = a->bias_axis;
   p.ws = a->workspace;
+  p.out16 = (bf16_raw*)a->out16; p.ld16 = a->ld16; p.stats_out = a->stats_out;
+  p.ln_stats = a->ln_stats; p.ln_colsum = a->ln_colsum; p.ln_eps = a->ln_eps;
+  if (p.out16) {          // producer of a folded LayerNorm: whole 32-column groups, vector stores, fp32 output
+    if (!p.stats_out || a->out_dtype != ODIC_F32 || a->batch != 1 || (a->N & 31) || (a->ldc & 7) || (a->ld16 & 7) ||
+        ((uintptr_t)a->out16 & 15) || ((uintptr_t)a->out & 15) || (a->residual && (a->ldr & 3)))
+      return ODIC_EINVAL;
+  }
+  if (p.ln_stats) {       // consumer: A's row moments come in K/32 groups
+    if (!p.ln_colsum || a->batch != 1 || (a->K & 31) || a->bias_axis != 0) return ODIC_EINVAL;
+  }
   // Tile choice = fewest "rounds x per-tile cost": a launch runs in ceil(tiles / resident slots)
   // rounds (256 CUs x 3 / 2 / 1 blocks for the 128x64 / 128x128 / 256x256 tiles, set by their LDS
   // footprints); relative per-tile costs 1 : 1.38 : 2.6 were measured on MI355X over the Swin-L
@@ -887,8 +953,15 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     case 9: return launch_cfg<2, 4, 8, 4, 2, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32 (64 KiB)
     case 10: return launch_cfg<4, 2, 4, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32, 3 stages (72 KiB)
     case 11: return launch_cfg<2, 4, 8, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32, 3 stages (96 KiB)
-    case 12: return launch_256sq(p, a->out_dtype, a->batch, stream);                 // 256 x 256 x 64, 4 phases per K-tile (128 KiB)
+    case 12: if (p.out16 || p.ln_stats) return ODIC_EUNSUPPORTED;
+             return launch_256sq(p, a->out_dtype, a->batch, stream);                 // 256 x 256 x 64, 4 phases per K-tile (128 KiB)
     // 16 + c: tile config c as a persistent, dynamically scheduled launch (needs args->workspace, batch == 1)
+    case 16: case 17: case 18: case 19: case 20: case 21: case 23: case 24: case 25: case 26: case 27:
+      if (p.out16 || p.ln_stats) return ODIC_EUNSUPPORTED;
+      break;
+    default: break;
+  }
+  switch (cfg) {
     case 16: return launch_persist<2, 2, 4, 2, 2>(p, a->out_dtype, a->batch, stream);
     case 17: return launch_persist<2, 2, 4, 4, 2>(p, a->out_dtype, a->batch, stream);
     case 18: return launch_persist<2, 4, 8, 4, 2>(p, a->out_dtype, a->batch, stream);

@@ -79,6 +79,18 @@ class SwinEngine:
                 down = dict(nw=f32(p + ".norm.weight"), nb=f32(p + ".norm.bias"), red_w=cw(p + ".reduction.weight"))
             self.stages.append((blocks, down))
         self.fn_w, self.fn_b = f32(f"{P}.norm.weight"), f32(f"{P}.norm.bias")
+        # bf16 mode: norm2 and the norm1 of every block but a stage's first are folded across the products around
+        # them (ops.gemm producer / consumer form): the proj / fc2 product leaves a bf16 copy of the residual stream
+        # plus row-group moments, the fc1 / next qkv product normalises in its epilogue.  ODIC_FOLD_BACKBONE_LN=0
+        # keeps the 48 separate LayerNorm launches.
+        self.fold_ln = precision == "bf16" and os.environ.get("ODIC_FOLD_BACKBONE_LN", "1") == "1" and \
+            all(g.stage_dim(s) % 64 == 0 for s in range(len(g.swin_depths)))
+        if self.fold_ln:
+            for s, (blocks, _) in enumerate(self.stages):
+                for b, w in enumerate(blocks):
+                    p = f"{P}.layers.{s}.blocks.{b}"
+                    w["qkv_f"] = ops.fold_layernorm_bf16(f32(p + ".attn.qkv.weight"), w["qkv_b"], w["n1w"], w["n1b"])
+                    w["fc1_f"] = ops.fold_layernorm_bf16(f32(p + ".mlp.fc1.weight"), w["fc1_b"], w["n2w"], w["n2b"])
         self.fp8_ready = False
         if fp8:
             self._pack_fp8(sd, calibration_images)
@@ -146,6 +158,24 @@ class SwinEngine:
                     h = ops.gemm(xn, w["fc1_w8"], w["fc1_b"], act=ops.ACT_GELU, col_scale=w["fc1_cs"],
                                  out_scale=w["hid_inv"], out_dtype=ops.FP8_DTYPE)
                     ops.gemm(h, w["fc2_w8"], w["fc2_b"], residual=x, out=x, col_scale=w["fc2_cs"])
+                elif self.fold_ln and _amax is None:
+                    if bi == 0:                                  # x comes from patch embed / patch merge: plain norm1
+                        x16 = torch.empty(x.shape, dtype=cdt, device=x.device)
+                        stats = torch.empty(x.shape[0], C_ // 32, 2, dtype=torch.float32, device=x.device)
+                        xn = ops.layernorm(x, w["n1w"], w["n1b"], out_dtype=cdt)
+                        qkv = ops.gemm(xn, w["qkv_w"], w["qkv_b"])
+                    else:                                        # norm1 folded: A = bf16 copy left by the previous fc2
+                        Wf, bf, cs = w["qkv_f"]
+                        qkv = ops.gemm(x16, Wf, bf, ln_fold=(cs, 1e-5), ln_stats=stats)
+                    att = ops.window_attention(qkv, w["table"], B, res, C_, heads, ws, w["shift"],
+                                               bias_shifted_prescaled=w["dense"])
+                    ops.gemm(att, w["proj_w"], w["proj_b"], residual=x, out=x, out16=x16, stats_out=stats)
+                    Wf, bf, cs = w["fc1_f"]
+                    h = ops.gemm(x16, Wf, bf, act=ops.ACT_GELU, ln_fold=(cs, 1e-5), ln_stats=stats)
+                    if bi + 1 < len(blocks):
+                        ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x, out16=x16, stats_out=stats)
+                    else:
+                        ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x)
                 else:
                     xn = ops.layernorm(x, w["n1w"], w["n1b"], out_dtype=cdt)
                     if _amax is not None:

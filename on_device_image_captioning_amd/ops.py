@@ -186,14 +186,19 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
          lda: Optional[int] = None, ldw: Optional[int] = None, ldr: Optional[int] = None,
          ldc: Optional[int] = None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideBias: int = 0,
          strideR: int = 0, strideC: int = 0, ln_fold: Optional[tuple] = None, tile_cfg: int = -1,
-         col_scale: Optional[torch.Tensor] = None, out_scale: float = 1.0) -> torch.Tensor:
+         col_scale: Optional[torch.Tensor] = None, out_scale: float = 1.0,
+         out16: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None,
+         ln_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = act(alpha·A·Wᵀ + bias) + residual.  With no explicit dims, A is [..., K] (flattened to
     [M,K]) and W is [N,K], both contiguous.  Explicit dims / leading dimensions / batch strides allow
     strided sub-matrices (elements).  ln_fold = (colsum, eps): W and bias come from fold_layernorm() and
     the rows of A are LayerNorm-ed inside the product (fp32 skinny-M path only).  fp8 / fp16 operands (the
     low-precision backbone mode): `col_scale` fp32 [N] multiplies column n of A·Wᵀ (activation scale x weight channel
-    scale) and `out_scale` the result before an fp8 / fp16 output cast."""
-    _need_cuda(A, W, bias, residual, out, col_scale)
+    scale) and `out_scale` the result before an fp8 / fp16 output cast.
+    LayerNorm folded across two bf16 products: the PRODUCER (fp32 output) is given `out16` (bf16 [M,N]) and
+    `stats_out` (fp32 [M, N/32, 2]); the CONSUMER reads that copy as A with `ln_stats=stats_out` and
+    `ln_fold=(colsum, eps)` from fold_layernorm_bf16()."""
+    _need_cuda(A, W, bias, residual, out, col_scale, out16, stats_out, ln_stats)
     if A.dtype != W.dtype:
         raise RuntimeError("A and W must share a dtype")
     if M is None:
@@ -222,11 +227,12 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
                       strideA, strideW, strideBias, strideR, strideC, alpha, act, bias_axis,
                       dtype_code(A.dtype), dtype_code(out.dtype), tile_cfg,
                       _p(ln_fold[0]) if ln_fold else None, float(ln_fold[1]) if ln_fold else 0.0, None,
-                      _p(col_scale), float(out_scale))
+                      _p(col_scale), float(out_scale), _p(out16), out16.stride(0) if out16 is not None else 0,
+                      _p(stats_out), _p(ln_stats))
     if A.dtype in (torch.bfloat16, torch.float16, FP8_DTYPE):
         if batch == 1 and A.dtype == torch.bfloat16:
             a.workspace = _gemm_workspace(A.device).data_ptr()
-        key = (A.dtype, M, N, K, batch, out.dtype, act, residual is not None)
+        key = (A.dtype, M, N, K, batch, out.dtype, act, residual is not None, out16 is not None, ln_stats is not None)
         cfg = _TILE_CHOICE.get(key) if tile_cfg < 0 else tile_cfg
         if cfg is None and tile_cfg < 0 and _TILE_CACHE:
             cfg = _TILE_CACHE.get(_cache_key(key))
@@ -255,6 +261,14 @@ def fold_layernorm(W: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.T
     Wg = W64 * gamma.double()[None, :]
     b2 = W64 @ beta.double() + (bias.double() if bias is not None else 0.0)
     return Wg.float().contiguous(), b2.float().contiguous(), Wg.sum(1).float().contiguous()
+
+
+def fold_layernorm_bf16(W: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """Weight-pack-time half of the LayerNorm folded across two bf16 products: (bf16 W·diag(gamma), fp32 bias + W·beta,
+    fp32 row sums of the ROUNDED bf16 weights — the kernel subtracts mean·colsum from a product of exactly those)."""
+    Wg, b2, _ = fold_layernorm(W, bias, gamma, beta)
+    W16 = Wg.to(torch.bfloat16).contiguous()
+    return W16, b2, W16.double().sum(1).float().contiguous()
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, eps: float = 1e-5,

@@ -622,3 +622,37 @@ def test_window_attention_fp16(ops, res, heads, shift):
                                bias_shifted_prescaled=ops.shifted_bias_prescaled(dev(table), ws, 32 ** -0.5))
     assert got.dtype == torch.float16
     assert_close(got, want, 2.5e-3, "window_attention fp16")
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm folded across two bf16 products
+@pytest.mark.parametrize("cfg", [0, 1, 7, 10])
+def test_gemm_bf16_layernorm_fold_producer_consumer(ops, cfg):
+    """Producer: a residual product (fp32 out) that also leaves the bf16 copy of its rows and their per-32-column
+    moments; consumer: the next product normalises those rows in its epilogue.  Checked: the copy is the rounded
+    output bit for bit, the moments are those of the bf16 values, and consumer == LayerNorm(copy)·Wᵀ + b in fp64
+    (with the packed bf16 W·diag(gamma)), for rows with a large common offset too (the centred combination)."""
+    M, C, N2 = 777, 384, 328
+    A0, W0 = rnd(M, 256, seed=1).bfloat16(), rnd(C, 256, seed=2, scale=0.08).bfloat16()
+    b0 = rnd(C, seed=3)
+    r = rnd(M, C, seed=4, scale=2.0) + 5.0 * rnd(M, 1, seed=5)          # per-row offset up to several sigma
+    x16 = torch.empty(M, C, dtype=torch.bfloat16, device="cuda")
+    stats = torch.empty(M, C // 32, 2, device="cuda")
+    x = ops.gemm(dev(A0), dev(W0), dev(b0), dev(r), out_dtype=torch.float32, out16=x16, stats_out=stats, tile_cfg=cfg)
+    want_x = A0.double() @ W0.double().T + b0.double() + r.double()
+    assert_close(x, want_x, 2e-5, "producer fp32 output")
+    assert torch.equal(x16.cpu(), x.cpu().bfloat16())
+    a = x16.cpu().double().view(M, C // 32, 32)
+    gm = a.mean(-1)
+    gm2 = ((a - gm[..., None]) ** 2).sum(-1)
+    assert_close(stats[..., 0], gm, 1e-5, "group means")
+    assert_close(stats[..., 1], gm2, 1e-4, "group centred sums of squares")
+    g, b = 1 + rnd(C, seed=6, scale=0.1), rnd(C, seed=7, scale=0.05)
+    W1, b1 = rnd(N2, C, seed=8, scale=0.05), rnd(N2, seed=9)
+    Wf, bf, cs = ops.fold_layernorm_bf16(dev(W1), dev(b1), dev(g), dev(b))
+    got = ops.gemm(x16, Wf, bf, act=1, ln_fold=(cs, 1e-5), ln_stats=stats, tile_cfg=cfg)
+    ad = x16.cpu().double()
+    norm = (ad - ad.mean(-1, keepdim=True)) / torch.sqrt(ad.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    want = torch.nn.functional.gelu(norm @ Wf.cpu().double().T + bf.cpu().double())
+    assert_close(got, want, 8e-3, "consumer (bf16 out)")
+    ln = torch.nn.functional.layer_norm(ad, (C,), g.double(), b.double())
+    assert_close(got, torch.nn.functional.gelu(ln @ W1.double().T + b1.double()), 1.5e-2, "consumer vs LayerNorm + Linear")
