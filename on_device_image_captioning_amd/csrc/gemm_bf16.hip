@@ -67,7 +67,9 @@ __device__ __forceinline__ int wperm(int r) {
   return (r & ~31) + 8 * ((r & 15) >> 2) + 4 * ((r >> 4) & 1) + (r & 3);
 }
 
-template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK, typename OutT>
+// LNF: 0 plain, 1 producer of a folded LayerNorm (fp32 out + bf16 copy + row-group moments), 2 consumer
+// (separate instantiations: the extra registers of the fold must not cost the plain products their occupancy)
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK, typename OutT, int LNF = 0>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) {
   constexpr int NW = NWM * NWN;
   constexpr int ROWB = BK * 2;                 // bytes per LDS row
@@ -148,19 +150,34 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
     if (t < nk) stage(t, t);
 
   // folded LayerNorm, consumer side: (mean, rstd) of this tile's BM rows of A from the per-32-column-group
-  // moments its producer left (Chan's combination of equal-sized groups) → LDS tail, read in the epilogue
+  // moments its producer left (Chan's combination of equal-sized groups) → LDS tail, read in the epilogue.
+  // Four lanes per row, each with a quarter of the K/32 groups in registers (all loads issued before the first
+  // use: a dependent load per group would cost more than the tile's whole K-loop).
   float2* s_stat = (float2*)(lds + NSTAGE * STAGE);
-  if (p.ln_stats) {
-    const int ng = p.K >> 5;
-    for (int r = tid; r < BM; r += 64 * NW) {
+  if constexpr (LNF == 2) {
+    const int ng = p.K >> 5;                                      // groups per row (<= 48); lane q takes q, q+4, ...
+    for (int t = tid; t < 4 * BM; t += 64 * NW) {
+      const int r = t >> 2, q = t & 3;
       const int row = min(m0 + r, p.M - 1);
-      const float2* st = (const float2*)p.ln_stats + (long)row * ng;
+      const float2* st = (const float2*)p.ln_stats + (long)row * ng + q;
+      float2 gv[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) gv[i] = q + 4 * i < ng ? st[4 * i] : make_float2(0.f, 0.f);
       float msum = 0.f;
-      for (int g = 0; g < ng; ++g) msum += st[g].x;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) msum += gv[i].x;
+      msum += __shfl_xor(msum, 1, 64);
+      msum += __shfl_xor(msum, 2, 64);
       const float mean = msum / (float)ng;
       float m2 = 0.f;
-      for (int g = 0; g < ng; ++g) { const float2 t = st[g]; const float d = t.x - mean; m2 += t.y + 32.0f * d * d; }
-      s_stat[r] = make_float2(mean, rsqrtf(m2 / (float)p.K + p.ln_eps));
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const float d = gv[i].x - mean;
+        m2 += q + 4 * i < ng ? gv[i].y + 32.0f * d * d : 0.f;
+      }
+      m2 += __shfl_xor(m2, 1, 64);
+      m2 += __shfl_xor(m2, 2, 64);
+      if (q == 0) s_stat[r] = make_float2(mean, rsqrtf(m2 / (float)p.K + p.ln_eps));
     }
   }
 
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       bc[e] = (bias && !p.bias_axis && col + e < p.N) ? bias[col + e] : 0.f;
-      cs[e] = (p.ln_stats && col + e < p.N) ? p.ln_colsum[col + e] : 0.f;
+      cs[e] = (LNF == 2 && col + e < p.N) ? p.ln_colsum[col + e] : 0.f;
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -216,12 +233,12 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
       if (row >= p.M) continue;
       const float brow = (bias && p.bias_axis) ? bias[row] : 0.f;
       float2 mr = make_float2(0.f, 1.f);
-      if (p.ln_stats) mr = s_stat[rloc];
+      if constexpr (LNF == 2) mr = s_stat[rloc];
       f32x4_t v[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         f32x4_t lin = acc[mi][2 * nq + h] * p.alpha;
-        if (p.ln_stats)
+        if constexpr (LNF == 2)
           lin = (lin - f32x4_t{cs[4 * h], cs[4 * h + 1], cs[4 * h + 2], cs[4 * h + 3]} * mr.x) * mr.y;
         f32x4_t pre = lin + f32x4_t{bc[4 * h], bc[4 * h + 1], bc[4 * h + 2], bc[4 * h + 3]} + brow;
         if (p.act == ODIC_ACT_GELU) {
@@ -240,7 +257,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) 
         OutT* dst = out + (long)row * p.ldc + col;
         if constexpr (sizeof(OutT) == 4) {
           ((f32x4_t*)dst)[0] = v[0]; ((f32x4_t*)dst)[1] = v[1];
-          if (p.out16) {
+          if constexpr (LNF == 1) {
             // folded LayerNorm, producer side: the bf16 copy the next product reads as its A operand, and the
             // moments of THOSE bf16 values over this row's 32-column group (the 4 fq lanes of a row hold it)
             bf16x8_t pk;
@@ -786,7 +803,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256sq_kernel(Params p) {
   }
 }
 
-template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK = 64>
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK = 64, bool FOLD = false>
 int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
   constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
   constexpr int SHMEM = NSTAGE * (BM + BN) * BK * 2 + BM * 8;          // + (mean, rstd) per row of the tile
@@ -815,6 +832,26 @@ int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
       (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
       done = true;
     }
+  }
+  if constexpr (FOLD) {             // folded-LayerNorm forms exist for the tile configurations the tuner picks from
+    auto kprod = gemm_bf16_nt_kernel<NWM, NWN, MI, NI, NSTAGE, BK, float, 1>;
+    auto kcons = gemm_bf16_nt_kernel<NWM, NWN, MI, NI, NSTAGE, BK, bf16_raw, 2>;
+    if (SHMEM > 64 * 1024) {
+      static bool done2 = false;
+      if (!done2) {
+        (void)hipFuncSetAttribute((const void*)kprod, hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+        (void)hipFuncSetAttribute((const void*)kcons, hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+        done2 = true;
+      }
+    }
+    if (p.out16) { hipLaunchKernelGGL(kprod, grid, block, SHMEM, stream, p); return odic_launch_status(); }
+    if (p.ln_stats) {
+      if (out_dtype != ODIC_BF16 || (p.K >> 5) > 48) return ODIC_EUNSUPPORTED;
+      hipLaunchKernelGGL(kcons, grid, block, SHMEM, stream, p);
+      return odic_launch_status();
+    }
+  } else {
+    if (p.out16 || p.ln_stats) return ODIC_EUNSUPPORTED;
   }
   if (out_dtype == ODIC_BF16) hipLaunchKernelGGL(kb, grid, block, SHMEM, stream, p);
   else hipLaunchKernelGGL(kf, grid, block, SHMEM, stream, p);
@@ -923,8 +960,8 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
         ((uintptr_t)a->out16 & 15) || ((uintptr_t)a->out & 15) || (a->residual && (a->ldr & 3)))
       return ODIC_EINVAL;
   }
-  if (p.ln_stats) {       // consumer: A's row moments come in K/32 groups
-    if (!p.ln_colsum || a->batch != 1 || (a->K & 31) || a->bias_axis != 0) return ODIC_EINVAL;
+  if (p.ln_stats) {       // consumer: A's row moments come in K/32 groups (a multiple of 4, at most 48)
+    if (!p.ln_colsum || a->batch != 1 || (a->K & 31) || a->K > 1536 || a->bias_axis != 0) return ODIC_EINVAL;
   }
   // Tile choice = fewest "rounds x per-tile cost": a launch runs in ceil(tiles / resident slots)
   // rounds (256 CUs x 3 / 2 / 1 blocks for the 128x64 / 128x128 / 256x256 tiles, set by their LDS
@@ -937,21 +974,21 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
       return (double)((t + slots - 1) / slots);
     };
     const double c0 = rounds(128, 64, 768) * 1.0, c1 = rounds(128, 128, 512) * 1.38;
-    const double c2 = (a->N % 256 == 0) ? rounds(256, 256, 256) * 2.6 : 1e30;
+    const double c2 = (a->N % 256 == 0 && !p.out16 && !p.ln_stats) ? rounds(256, 256, 256) * 2.6 : 1e30;   // (no folded-LN form)
     cfg = (c0 <= c1 && c0 <= c2) ? 0 : (c1 <= c2 ? 1 : 2);
   }
   switch (cfg) {
-    case 0: return launch_cfg<2, 2, 4, 2, 2>(p, a->out_dtype, a->batch, stream);     // 128 x 64, 2 stages
-    case 1: return launch_cfg<2, 2, 4, 4, 2>(p, a->out_dtype, a->batch, stream);     // 128 x 128
+    case 0: return launch_cfg<2, 2, 4, 2, 2, 64, true>(p, a->out_dtype, a->batch, stream);     // 128 x 64, 2 stages
+    case 1: return launch_cfg<2, 2, 4, 4, 2, 64, true>(p, a->out_dtype, a->batch, stream);     // 128 x 128
     case 2: return launch_cfg<2, 4, 8, 4, 2>(p, a->out_dtype, a->batch, stream);     // 256 x 256
     case 3: return launch_cfg<2, 2, 4, 2, 3>(p, a->out_dtype, a->batch, stream);     // 128 x 64, 3 stages
     case 4: return launch_cfg<2, 2, 4, 4, 3>(p, a->out_dtype, a->batch, stream);     // 128 x 128, 3 stages
     case 5: return launch_cfg<4, 2, 4, 4, 3>(p, a->out_dtype, a->batch, stream);     // 256 x 128, 3 stages (144 KiB)
     case 6: return launch_cfg<2, 2, 4, 2, 4>(p, a->out_dtype, a->batch, stream);     // 128 x 64, 4 stages
-    case 7: return launch_cfg<4, 2, 4, 4, 2, 32>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32 (48 KiB)
+    case 7: return launch_cfg<4, 2, 4, 4, 2, 32, true>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32 (48 KiB)
     case 8: return launch_cfg<2, 2, 4, 4, 2, 32>(p, a->out_dtype, a->batch, stream); // 128 x 128 x 32 (32 KiB)
     case 9: return launch_cfg<2, 4, 8, 4, 2, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32 (64 KiB)
-    case 10: return launch_cfg<4, 2, 4, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32, 3 stages (72 KiB)
+    case 10: return launch_cfg<4, 2, 4, 4, 3, 32, true>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32, 3 stages (72 KiB)
     case 11: return launch_cfg<2, 4, 8, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32, 3 stages (96 KiB)
     case 12: if (p.out16 || p.ln_stats) return ODIC_EUNSUPPORTED;
              return launch_256sq(p, a->out_dtype, a->batch, stream);                 // 256 x 256 x 64, 4 phases per K-tile (128 KiB)

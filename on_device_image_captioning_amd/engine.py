@@ -79,11 +79,13 @@ class SwinEngine:
                 down = dict(nw=f32(p + ".norm.weight"), nb=f32(p + ".norm.bias"), red_w=cw(p + ".reduction.weight"))
             self.stages.append((blocks, down))
         self.fn_w, self.fn_b = f32(f"{P}.norm.weight"), f32(f"{P}.norm.bias")
-        # bf16 mode: norm2 and the norm1 of every block but a stage's first are folded across the products around
-        # them (ops.gemm producer / consumer form): the proj / fc2 product leaves a bf16 copy of the residual stream
-        # plus row-group moments, the fc1 / next qkv product normalises in its epilogue.  ODIC_FOLD_BACKBONE_LN=0
-        # keeps the 48 separate LayerNorm launches.
-        self.fold_ln = precision == "bf16" and os.environ.get("ODIC_FOLD_BACKBONE_LN", "1") == "1" and \
+        # Optional (ODIC_FOLD_BACKBONE_LN=1, bf16 mode): norm2 and the norm1 of every block but a stage's first folded
+        # across the products around them (ops.gemm producer / consumer form): the proj / fc2 product leaves a bf16
+        # copy of the residual stream plus row-group moments, the fc1 / next qkv product normalises in its epilogue.
+        # Equally accurate (tools/fold_diag.py) and 44 launches fewer, but measured 1.5 % SLOWER end to end: the
+        # LayerNorm kernels already run at 5 TB/s, and the producer's extra stores + the consumer's moment combine
+        # cost the four products of a block 20 µs against the 16 µs of the two launches they replace.
+        self.fold_ln = precision == "bf16" and os.environ.get("ODIC_FOLD_BACKBONE_LN", "0") == "1" and \
             all(g.stage_dim(s) % 64 == 0 for s in range(len(g.swin_depths)))
         if self.fold_ln:
             for s, (blocks, _) in enumerate(self.stages):
