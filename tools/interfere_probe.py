@@ -28,6 +28,8 @@ out_5d = torch.empty(N, 5 * d, device=dev)
 out_ff = torch.empty(N, g.ff, device=dev)
 cands = {
     "none": None,
+    "trivial kernel, 1 block (launch cost only)": lambda: ops.beam_reset(st.beam_state, st.n_img, st.beams, st.T, 79),
+    "dec_embed 48 blocks": lambda: ops.dec_embed(st.next_tok, cap.embed, cap.pos_table, st.pos, st.ycat, 3 * d, N, d, 22.6),
     "layernorm 48x512": lambda: ops.layernorm(x, w["n1w"], w["n1b"], M=N, C_=d, ldx=d),
     "gemm dyn 512->2560 (160 blk)": lambda: ops.gemm(x, w["dyn_w"], w["dyn_b"], out=out_5d),
     "gemm wq 512->512 (32 blk)": lambda: ops.gemm(x, w["wq"], w["bq"], out=out_d),
@@ -38,7 +40,8 @@ cands = {
                                                    g.vocab_size, 3),
     "cross_attn": lambda: ops.cross_attn_step(x, d, st.kv, st.kv.shape[2], 0, d, st.enc_len, st.row_valid, out_d, d, N,
                                               st.n_img, st.S, d, g.num_heads),
-    "full decode step": lambda: pipe._step(0),
+    # (the step advances *pos: re-arm the state every time, or the prefixes run past their T positions)
+    "full decode step": lambda: (ops.beam_reset(st.beam_state, st.n_img, st.beams, st.T, 79), pipe._step(0)),
 }
 s2 = torch.cuda.Stream()
 NL = 64
@@ -78,7 +81,7 @@ for name, fn in cands.items():
     if gr is None:
         print(f"{name:34s} encode {enc:7.3f} ms")
     else:
-        per = 39 * 4 if name == "full decode step" else NL
+        per = 30 * 4 if name == "full decode step" else NL
         kt = k0.elapsed_time(k1)
         print(f"{name:34s} encode {enc:7.3f} ms | side stream busy {kt:7.2f} ms, {1e3 * kt / (nrep * per):6.2f} us per launch "
               f"({nrep * per} launches)")
