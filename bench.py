@@ -45,7 +45,7 @@ if ROOT not in sys.path:
 
 PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}     # MI355X_MICROARCH.md
 SOS, EOS = 79, 77
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic_{workload}.json")     # collected per workload
 
 WORKLOADS = {
     "e2e16": dict(
@@ -241,23 +241,26 @@ def kernel_source_hash() -> str:
 
 
 _PMC = None
+_PMC_PATH = None
 
 
-def pmc_traffic(name):
-    """HBM bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate runs of this very command; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
-    prescribes; tools/pmc_traffic_json.py).  bench.py cannot read hardware counters itself."""
-    global _PMC
+def pmc_traffic(name, workload=None):
+    """HBM bytes per launch of a kernel family from the committed PMC passes of THIS workload (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs of this very command; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
+    prescribes; tools/collect_profiles.sh, tools/pmc_traffic_json.py); None where no pass was collected.
+    bench.py cannot read hardware counters itself."""
+    global _PMC, _PMC_PATH
     if _PMC is None:
+        _PMC_PATH = PMC_FILE.format(workload=workload or "e2e16")
         try:
-            with open(PMC_FILE) as f:
+            with open(_PMC_PATH) as f:
                 _PMC = json.load(f)
         except OSError:
             _PMC = {}
     return _PMC.get(name, {}).get("hbm_bytes_per_launch")
 
 
-def roofline_entry(name, d):
+def roofline_entry(name, d, workload=None):
     sec = d["ms"] * 1e-3
     mfma = name.startswith("gemm") or name.startswith("swin_attention_block")
     if mfma:
@@ -270,7 +273,7 @@ def roofline_entry(name, d):
         ach = d["bytes"] / sec / 1e9
         e = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK["hbm_gbs"], "unit": "GB/s",
              "frac": round(ach / PEAK["hbm_gbs"], 4), "algorithmic_bytes_per_step": d["bytes"]}
-    e.update({"traffic": pmc_traffic(name), "launches": d["launches"],
+    e.update({"traffic": pmc_traffic(name, workload), "launches": d["launches"],
               "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
               "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"])})
     return e
@@ -451,12 +454,12 @@ def main():
             fam = roofline_pass(pipe, images)
             derived = {n: fam.pop(n) for n in list(fam) if n.startswith("swin_attention_block")}
             total_ms = sum(d["ms"] for d in fam.values())
-            entries = sorted((roofline_entry(n, d) for n, d in fam.items()), key=lambda e: -fam[e["kernel"]]["ms"])
+            entries = sorted((roofline_entry(n, d, a.workload) for n, d in fam.items()), key=lambda e: -fam[e["kernel"]]["ms"])
             for e in entries:
                 e["time_share"] = round(fam[e["kernel"]]["ms"] / total_ms, 4)
             out["roofline"] = entries[0]
             for n, d in derived.items():             # three launches per Swin block, already counted above
-                e = roofline_entry(n, d)
+                e = roofline_entry(n, d, a.workload)
                 e["time_share"] = round(d["ms"] / total_ms, 4)
                 e["note"] = ("fused-form accounting of SURVEY 8(d): algorithmic FLOPs of qkv Linear + attention core + "
                              "proj Linear per Swin block over the summed durations of those three launches")
@@ -465,8 +468,9 @@ def main():
             out["roofline_note"] = ("achieved = algorithmic FLOPs (2·M·N·K per GEMM) or bytes (DESIGN.md §4 per family) ÷ Σ "
                                     "HIP-event durations of that kernel family in one instrumented eager pass of the same "
                                     "step; traffic = measured HBM bytes per launch (average over the family) from the "
-                                    "committed rocprofv3 PMC passes, " + os.path.relpath(PMC_FILE, ROOT))
-            out["traffic_source"] = {"file": os.path.relpath(PMC_FILE, ROOT), "kernel_source_hash_then": src.get("kernel_source_hash"),
+                                    "committed rocprofv3 PMC passes of this workload (null where none was collected)")
+            out["traffic_source"] = {"file": os.path.relpath(_PMC_PATH, ROOT) if _PMC else None,
+                                     "kernel_source_hash_then": src.get("kernel_source_hash"),
                                      "kernel_source_hash_now": kernel_source_hash(),
                                      "stale": src.get("kernel_source_hash") != kernel_source_hash()}
             out["kernels"] = entries

@@ -20,7 +20,7 @@ F=$(find $OUT/fetch -name "*counter_collection.csv" | head -1)
 W=$(find $OUT/write -name "*counter_collection.csv" | head -1)
 S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 python3 tools/summarize_pmc.py $F $W > $OUT/pmc_hbm_traffic.txt
-python3 tools/pmc_traffic_json.py $F $W $OUT/pmc_traffic.json "$CMD (tile choices preloaded: no tuning launches)"
+python3 tools/pmc_traffic_json.py $F $W $OUT/pmc_traffic_$WL.json "$CMD (tile choices preloaded: no tuning launches)"
 cut -c1-220 $S | head -60 > $OUT/kernel_stats.csv
 rm -rf $OUT/fetch $OUT/write $OUT/trace/*/*kernel_trace.csv
 echo collected
