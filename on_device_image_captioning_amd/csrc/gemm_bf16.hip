@@ -990,6 +990,9 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     case 9: return launch_cfg<2, 4, 8, 4, 2, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32 (64 KiB)
     case 10: return launch_cfg<4, 2, 4, 4, 3, 32, true>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32, 3 stages (72 KiB)
     case 11: return launch_cfg<2, 4, 8, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32, 3 stages (96 KiB)
+    case 13: return launch_cfg<4, 4, 4, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32, 16 waves of 64 x 64, 3 stages (96 KiB)
+    case 14: return launch_cfg<4, 4, 4, 4, 2, 64>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 64, 16 waves of 64 x 64, 2 stages (128 KiB)
+    case 15: return launch_cfg<4, 4, 4, 4, 4, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32, 16 waves, 4 stages (128 KiB)
     case 12: if (p.out16 || p.ln_stats) return ODIC_EUNSUPPORTED;
              return launch_256sq(p, a->out_dtype, a->batch, stream);                 // 256 x 256 x 64, 4 phases per K-tile (128 KiB)
     // 16 + c: tile config c as a persistent, dynamically scheduled launch (needs args->workspace, batch == 1)
