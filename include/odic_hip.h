@@ -43,7 +43,7 @@ extern "C" {
 #define ODIC_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ODIC_ABI_VERSION 11
+#define ODIC_ABI_VERSION 12
 int odic_abi_version(void);
 
 /* Human-readable build string ("gfx950 hipcc ..."), static storage. */
@@ -215,7 +215,10 @@ int odic_dec_embed(const int64_t* tokens, const float* embed, const float* pos_t
  *        LN1(y) at `pos`
  *   qexp, bexp fp32 [E, d]: query_exp_vectors / bias_exp_vectors
  *   caches (fp32), indexed [pos][seq_slot]:  cond_c, key_c, va_c, vb_c  [T, N, d]
- *                                            afull_c, bfull_c  [T, N, E, d] (class_a/b + bias, :199-200)
+ *                                            wfa_c, wfb_c  [T, N, T, E] — the normalised FORWARD weights of that
+ *                                               position's E expansion queries over its keys 0..pos (:165-176);
+ *                                               the (t·E) x d class matrices of :177-180,199-200 are never formed:
+ *                                               the backward sum of :183-200 is re-associated onto va / vb / cond
  *                                            qk_c [T, N, E]   (query_exp[e]·key of that position)
  *   anc int32 [N, T]: for sequence n and position j < pos, the slot (sequence index) whose cache
  *        entry at j belongs to n's history (beam re-ordering without copying caches); position
@@ -223,12 +226,12 @@ int odic_dec_embed(const int64_t* tokens, const float* embed, const float* pos_t
  *   row_valid int32 [N]: 0 → padded row (finished beam): the block contributes 0 (masked rows of
  *        utils/masking.py:37-47), caches are still written.
  *   y_in fp32 [N,d] (ldy_in) → y fp32 [N,d] (ldy):  y = y_in + sel·A' + (1-sel)·B'  (may alias).
- *   scratch fp32 [N, 4·T·E + T]: normalised weight tables handed from the score kernel to the
- *        accumulation kernel.   T <= 128, E in {4, 8, 16, 32}.
+ *   scratch fp32 [N, 5·T + 2·E]: coefficient vectors handed from the score kernel to the accumulation
+ *        kernel.   T <= 128, E in {4, 8, 16, 32}.
  */
 int odic_dynexp_step(const float* lin, int64_t ldlin, const float* qexp, const float* bexp,
-                     float* cond_c, float* key_c, float* va_c, float* vb_c, float* afull_c,
-                     float* bfull_c, float* qk_c, const int32_t* anc, const int32_t* row_valid,
+                     float* cond_c, float* key_c, float* va_c, float* vb_c, float* wfa_c,
+                     float* wfb_c, float* qk_c, const int32_t* anc, const int32_t* row_valid,
                      const int32_t* pos, const float* y_in, int64_t ldy_in, float* y, int64_t ldy,
                      float* scratch, int32_t N, int32_t T, int32_t d, int32_t E, float eps, void* stream);
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libodic_hip.so")
 
 F32, BF16, FP8, F16 = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _ERR = {-1: "ODIC_EINVAL (bad shape / alignment / enum)", -2: "ODIC_ENULL (required pointer is NULL)",
         -3: "ODIC_EUNSUPPORTED"}

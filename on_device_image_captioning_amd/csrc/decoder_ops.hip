@@ -55,47 +55,58 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const long long* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// One block per sequence.  With t = *pos and slot(j) = (j < t ? anc[n][j] : n):
-//   forward  z_fw[e][j] = (qexp[e] + cond_t)·key_j / sqrt(d)            j <= t
-//            A[e] = Σ_j relu(z_fw)[e][j]/(Σ_j relu(z_fw)[e][j] + eps) · va_j          (same with -z, vb)
-//            afull_t[e] = A[e] + bexp[e] + cond_t                                       (cached)
+// Dynamic expansion for the newest position.  With t = *pos and slot(j) = (j < t ? anc[n][j] : n):
+//   forward  z_fw[e][i] = (qexp[e] + cond_t)·key_i / sqrt(d)            i <= t
+//            wfa_t[i][e] = relu(z_fw)/(Σ_i relu(z_fw) + eps),  wfb_t with -z        (CACHED: (t+1)·E scalars each)
+//            class vectors of the reference:  afull_t[e] = Σ_i wfa_t[i][e]·va_i + bexp[e] + cond_t   (never formed)
 //   backward z_bw[j][e] = (qexp[e] + cond_j)·key_t / sqrt(d)            j <= t
-//            out_a = Σ_{j,e} relu(z_bw)[j][e]/(Σ relu(z_bw) + eps) · afull_j[e]        (same with -z, bfull)
+//            wba[j][e] = relu(z_bw)/(Σ_{j,e} relu(z_bw) + eps),  wbb with -z
+//            out_a = Σ_{j,e} wba[j][e]·afull_j[e]
+//                  = Σ_i ca[i]·va_i + Σ_e wea[e]·bexp[e] + Σ_j wja[j]·cond_j
+//              with ca[i] = Σ_{j>=i} Σ_e wba[j][e]·wfa_j[i][e],  wea[e] = Σ_j wba[j][e],  wja[j] = Σ_e wba[j][e]
 //   y_out = y_in + σ(sel)·out_a + (1-σ(sel))·out_b        (nothing is added on a padded row)
+// The reference (layers.py:152-204) materialises the (t·E) x d class matrices every step; a cache of afull / bfull
+// per position would be 2·E·d floats per position and sequence (64 KB at E = 16, d = 512: 100 MB read per step at
+// t = 10 for 48 sequences x 3 layers, streamed beside the encoder's GEMMs).  Re-associating the double sum moves the
+// cache to the forward WEIGHTS — (t+1)·E scalars per position — and the step to 3·(t+1) + E rows of d floats per
+// sequence: 8x fewer bytes, same arithmetic up to summation order.
 // The dot products split as qexp[e]·key + cond·key; qexp[e]·key_j is cached per position (qk_c).
 // ---------------------------------------------------------------------------------------------
 struct DynParams {
   const float* lin; long ldlin; const float* qexp; const float* bexp;
-  float* cond_c; float* key_c; float* va_c; float* vb_c; float* afull_c; float* bfull_c; float* qk_c;
+  float* cond_c; float* key_c; float* va_c; float* vb_c; float* wfa_c; float* wfb_c; float* qk_c;
   const int* anc; const int* row_valid; const int* pos; const float* y_in; long ldyi; float* y; long ldy;
-  float* scratch;                 // [N][4*T*E floats + T ints]
+  float* scratch;                 // [N][5*T + 2*E floats]
   int N, T, d, E; float eps;
 };
 
-// scratch layout per sequence (floats): wfa[T][E] | wfb[T][E] | wba[T][E] | wbb[T][E] | slot[T] (int)
-__device__ __forceinline__ long dyn_scratch_stride(int T, int E) { return 4L * T * E + T; }
+// scratch layout per sequence (floats): ca[T] | cb[T] | wja[T] | wjb[T] | wea[E] | web[E] | slot[T] (int)
+__device__ __forceinline__ long dyn_scratch_stride(int T, int E) { return 5L * T + 2L * E; }
 
-// Kernel 1 (one block per sequence, 512 threads): cache writes, the 2t+E+1 dot products (one per
-// 16-lane group, 32 in flight per block, float4 loads), all four normalised weight tables → scratch.
+// Kernel 1 (one block per sequence, 512 threads): cache writes, the 2t+E+1 dot products (one per 16-lane group,
+// 32 in flight per block, float4 loads), the normalised forward / backward weights, and the coefficients of
+// the re-associated sum → scratch.
 __global__ __launch_bounds__(512) void dynexp_scores_kernel(DynParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int d = p.d, E = p.E, n = blockIdx.x, tid = threadIdx.x;
+  const int d = p.d, E = p.E, T = p.T, n = blockIdx.x, tid = threadIdx.x;
   const int t = *p.pos;
   float* cond_t = sm;                  // [d]
   float* key_t = cond_t + d;           // [d]
-  float* dk = key_t + d;               // [MAX_T]  cond_t·key_j
-  float* ck = dk + MAX_T;              // [MAX_T]  cond_j·key_t
-  float* qk_t = ck + MAX_T;            // [MAX_E]  qexp[e]·key_t
+  float* dk = key_t + d;               // [T]  cond_t·key_j
+  float* ck = dk + T;                  // [T]  cond_j·key_t
+  float* qk_t = ck + T;                // [MAX_E]  qexp[e]·key_t
   float* nfw = qk_t + MAX_E;           // [2*MAX_E] 1/(Σ_j relu(±z_fw[e][·]) + eps)
   float* red = nfw + 2 * MAX_E;        // [8]
-  int* slot = (int*)(red + 8);         // [MAX_T]
-  float* qkh = (float*)(slot + MAX_T); // [MAX_T*E]  qexp[e]·key_j history
+  int* slot = (int*)(red + 8);         // [T]
+  float* qkh = (float*)(slot + T);     // [T*E]  qexp[e]·key_j history
+  float* wba = qkh + T * E;            // [T*E]  backward weights of this step
+  float* wbb = wba + T * E;            // [T*E]
 
   const float* lin = p.lin + (long)n * p.ldlin;
   const float inv_sqrt_d = rsqrtf((float)d);
   const long NT = (long)p.N;
-  float* scr = p.scratch + (long)n * dyn_scratch_stride(p.T, E);
-  const int TE = p.T * E;
+  float* scr = p.scratch + (long)n * dyn_scratch_stride(T, E);
+  const int TE = T * E;
 
   for (int c = tid; c < d; c += 512) {
     const float cv = lin[c], kv = lin[d + c];
@@ -104,9 +115,9 @@ __global__ __launch_bounds__(512) void dynexp_scores_kernel(DynParams p) {
     p.cond_c[o] = cv; p.key_c[o] = kv; p.va_c[o] = lin[2 * d + c]; p.vb_c[o] = lin[3 * d + c];
   }
   for (int j = tid; j <= t; j += 512) {
-    const int sl = j < t ? p.anc[(long)n * p.T + j] : n;
+    const int sl = j < t ? p.anc[(long)n * T + j] : n;
     slot[j] = sl;
-    ((int*)(scr + 4 * TE))[j] = sl;
+    ((int*)(scr + 4 * T + 2 * E))[j] = sl;
   }
   __syncthreads();
   for (int i = tid; i < t * E; i += 512) {
@@ -165,79 +176,90 @@ __global__ __launch_bounds__(512) void dynexp_scores_kernel(DynParams p) {
   const float ibp = 1.0f / (block_sum(bp, red) + p.eps);
   const float ibn = 1.0f / (block_sum(bn, red) + p.eps);
   __syncthreads();
+  // forward weights of THIS position → cache rows [t][n][i*E + e] (read by every later step of its descendants);
+  // backward weights of this step → LDS
+  float* wfa_t = p.wfa_c + ((long)t * NT + n) * TE;
+  float* wfb_t = p.wfb_c + ((long)t * NT + n) * TE;
   for (int i = tid; i < (t + 1) * E; i += 512) {
     const int j = i / E, e = i - j * E;
     const float q = j < t ? qkh[i] : qk_t[e];
     const float zf = (q + dk[j]) * inv_sqrt_d;
     const float zb = (qk_t[e] + ck[j]) * inv_sqrt_d;
-    scr[i] = fmaxf(zf, 0.f) * nfw[e];
-    scr[TE + i] = fmaxf(-zf, 0.f) * nfw[MAX_E + e];
-    scr[2 * TE + i] = fmaxf(zb, 0.f) * ibp;
-    scr[3 * TE + i] = fmaxf(-zb, 0.f) * ibn;
+    wfa_t[i] = fmaxf(zf, 0.f) * nfw[e];
+    wfb_t[i] = fmaxf(-zf, 0.f) * nfw[MAX_E + e];
+    wba[i] = fmaxf(zb, 0.f) * ibp;
+    wbb[i] = fmaxf(-zb, 0.f) * ibn;
+  }
+  __syncthreads();                        // (also orders the block's own wfa_t / wfb_t stores before the reads below)
+  // coefficients ca[i] = Σ_{j>=i} Σ_e wba[j][e]·wfa_j[i][e] (and cb): 4 lanes per key position i, lane q takes
+  // j = i+q, i+q+4, ...; fixed shuffle order → bit-identical run to run
+  for (int w = tid; w < 4 * (t + 1); w += 512) {
+    const int i = w >> 2, q = w & 3;
+    float sa = 0.f, sb = 0.f;
+    for (int j = i + q; j <= t; j += 4) {
+      const long row = ((long)j * NT + slot[j]) * TE + (long)i * E;
+      const float* fa = p.wfa_c + row;
+      const float* fb = p.wfb_c + row;
+      const float* ba = wba + j * E;
+      const float* bb = wbb + j * E;
+      for (int e = 0; e < E; e += 4) {
+        const float4 x = *(const float4*)(fa + e), y = *(const float4*)(fb + e);
+        sa = fmaf(ba[e], x.x, sa); sa = fmaf(ba[e + 1], x.y, sa); sa = fmaf(ba[e + 2], x.z, sa); sa = fmaf(ba[e + 3], x.w, sa);
+        sb = fmaf(bb[e], y.x, sb); sb = fmaf(bb[e + 1], y.y, sb); sb = fmaf(bb[e + 2], y.z, sb); sb = fmaf(bb[e + 3], y.w, sb);
+      }
+    }
+    sa += __shfl_xor(sa, 1, 64); sa += __shfl_xor(sa, 2, 64);
+    sb += __shfl_xor(sb, 1, 64); sb += __shfl_xor(sb, 2, 64);
+    if (q == 0) { scr[i] = sa; scr[T + i] = sb; }
+  }
+  for (int j = tid; j <= t; j += 512) {           // wja[j] = Σ_e wba[j][e]
+    float sa = 0.f, sb = 0.f;
+    for (int e = 0; e < E; ++e) { sa += wba[j * E + e]; sb += wbb[j * E + e]; }
+    scr[2 * T + j] = sa; scr[3 * T + j] = sb;
+  }
+  for (int e = tid; e < E; e += 512) {            // wea[e] = Σ_j wba[j][e]
+    float sa = 0.f, sb = 0.f;
+    for (int j = 0; j <= t; ++j) { sa += wba[j * E + e]; sb += wbb[j * E + e]; }
+    scr[4 * T + e] = sa; scr[4 * T + E + e] = sb;
   }
 }
 
-// Kernel 2 (grid N x d/128, 128 threads, one channel per thread): the weighted sums over cached
-// class vectors.  All loads of one j are independent (2·E in flight per thread), coalesced over c.
-template <int EE>
+// Kernel 2 (grid N x d/128, 128 threads, one channel per thread): the re-associated sums over the cached value,
+// condition and bias rows.  3·(t+1) + E independent, coalesced loads per thread.
 __global__ __launch_bounds__(128) void dynexp_accum_kernel(DynParams p) {
-  extern __shared__ float w[];             // 4 x [T][EE] weight tables + [T] slots — sized by T, not MAX_T
-  const int TS = p.T * EE;
-  int* slot = (int*)(w + 4 * TS);
+  extern __shared__ float w[];             // ca | cb | wja | wjb [T each] | wea | web [E each] | slot [T]
+  const int T = p.T, E = p.E;
   const int d = p.d, n = blockIdx.x, tid = threadIdx.x;
   const int c = blockIdx.y * 128 + tid;
   const int t = *p.pos;
   const long NT = (long)p.N;
-  const int TE = p.T * EE;
-  const float* scr = p.scratch + (long)n * dyn_scratch_stride(p.T, EE);
-  const int used = (t + 1) * EE;
-  for (int i = tid; i < used; i += 128) {
-    w[i] = scr[i]; w[TS + i] = scr[TE + i];
-    w[2 * TS + i] = scr[2 * TE + i]; w[3 * TS + i] = scr[3 * TE + i];
-  }
-  for (int j = tid; j <= t; j += 128) slot[j] = ((const int*)(scr + 4 * TE))[j];
+  const float* scr = p.scratch + (long)n * dyn_scratch_stride(T, E);
+  const int nw = 4 * T + 2 * E;
+  for (int i = tid; i < nw; i += 128) w[i] = scr[i];
+  int* slot = (int*)(w + nw);
+  for (int j = tid; j <= t; j += 128) slot[j] = ((const int*)(scr + nw))[j];
   __syncthreads();
   if (c >= d) return;
-  const float* wfa = w; const float* wfb = w + TS;
-  const float* wba = w + 2 * TS; const float* wbb = w + 3 * TS;
+  const float* ca = w; const float* cb = w + T;
+  const float* wja = w + 2 * T; const float* wjb = w + 3 * T;
+  const float* wea = w + 4 * T; const float* web = wea + E;
   const float* lin = p.lin + (long)n * p.ldlin;
 
-  float fa[EE], fb[EE];
-#pragma unroll
-  for (int e = 0; e < EE; ++e) { fa[e] = 0.f; fb[e] = 0.f; }
+  float oa = 0.f, ob = 0.f;
 #pragma unroll 4
   for (int j = 0; j <= t; ++j) {
     const long o = ((long)j * NT + slot[j]) * d + c;
     const float va = j < t ? p.va_c[o] : lin[2 * d + c];
     const float vb = j < t ? p.vb_c[o] : lin[3 * d + c];
-#pragma unroll
-    for (int e = 0; e < EE; ++e) {
-      fa[e] = fmaf(wfa[j * EE + e], va, fa[e]);
-      fb[e] = fmaf(wfb[j * EE + e], vb, fb[e]);
-    }
+    const float cj = j < t ? p.cond_c[o] : lin[c];
+    oa = fmaf(ca[j], va, oa); oa = fmaf(wja[j], cj, oa);
+    ob = fmaf(cb[j], vb, ob); ob = fmaf(wjb[j], cj, ob);
   }
-  const float cv = lin[c];
-  float oa = 0.f, ob = 0.f;
-#pragma unroll
-  for (int e = 0; e < EE; ++e) {
-    const float bias = p.bexp[(long)e * d + c] + cv;
-    const float af = fa[e] + bias, bf = fb[e] + bias;
-    const long o = (((long)t * NT + n) * EE + e) * d + c;
-    p.afull_c[o] = af; p.bfull_c[o] = bf;
-    oa = fmaf(wba[t * EE + e], af, oa);
-    ob = fmaf(wbb[t * EE + e], bf, ob);
-  }
-#pragma unroll 2
-  for (int j = 0; j < t; ++j) {
-    const long base = (((long)j * NT + slot[j]) * EE) * d + c;
-    float av[EE], bv[EE];
-#pragma unroll
-    for (int e = 0; e < EE; ++e) { av[e] = p.afull_c[base + (long)e * d]; bv[e] = p.bfull_c[base + (long)e * d]; }
-#pragma unroll
-    for (int e = 0; e < EE; ++e) {
-      oa = fmaf(wba[j * EE + e], av[e], oa);
-      ob = fmaf(wbb[j * EE + e], bv[e], ob);
-    }
+#pragma unroll 4
+  for (int e = 0; e < E; ++e) {
+    const float be = p.bexp[(long)e * d + c];
+    oa = fmaf(wea[e], be, oa);
+    ob = fmaf(web[e], be, ob);
   }
   float yv = p.y_in[(long)n * p.ldyi + c];
   if (p.row_valid[n]) {
@@ -747,33 +769,27 @@ extern "C" int odic_dec_embed(const int64_t* tokens, const float* embed, const f
 }
 
 extern "C" int odic_dynexp_step(const float* lin, int64_t ldlin, const float* qexp, const float* bexp,
-                                float* cond_c, float* key_c, float* va_c, float* vb_c, float* afull_c,
-                                float* bfull_c, float* qk_c, const int32_t* anc, const int32_t* row_valid,
+                                float* cond_c, float* key_c, float* va_c, float* vb_c, float* wfa_c,
+                                float* wfb_c, float* qk_c, const int32_t* anc, const int32_t* row_valid,
                                 const int32_t* pos, const float* y_in, int64_t ldy_in, float* y, int64_t ldy,
                                 float* scratch, int32_t N, int32_t T, int32_t d, int32_t E, float eps, void* stream) {
-  if (!lin || !qexp || !bexp || !cond_c || !key_c || !va_c || !vb_c || !afull_c || !bfull_c || !qk_c || !anc ||
+  if (!lin || !qexp || !bexp || !cond_c || !key_c || !va_c || !vb_c || !wfa_c || !wfb_c || !qk_c || !anc ||
       !row_valid || !pos || !y || !y_in || !scratch)
     return ODIC_ENULL;
   if (N <= 0 || T <= 0 || T > MAX_T || d <= 0 || E <= 0 || E > MAX_E) return ODIC_EINVAL;
   if (E != 4 && E != 8 && E != 16 && E != 32) return ODIC_EUNSUPPORTED;
   DynParams p;
   p.lin = lin; p.ldlin = ldlin; p.qexp = qexp; p.bexp = bexp; p.cond_c = cond_c; p.key_c = key_c; p.va_c = va_c;
-  p.vb_c = vb_c; p.afull_c = afull_c; p.bfull_c = bfull_c; p.qk_c = qk_c; p.anc = anc; p.row_valid = row_valid;
+  p.vb_c = vb_c; p.wfa_c = wfa_c; p.wfb_c = wfb_c; p.qk_c = qk_c; p.anc = anc; p.row_valid = row_valid;
   p.pos = pos; p.y_in = y_in; p.ldyi = ldy_in; p.y = y; p.ldy = ldy; p.scratch = scratch;
   p.N = N; p.T = T; p.d = d; p.E = E; p.eps = eps;
   hipStream_t s = (hipStream_t)stream;
   if (d % 64) return ODIC_EINVAL;
-  const size_t shmem = (size_t)(2 * d + 2 * MAX_T + MAX_E + 2 * MAX_E + 8 + MAX_T * E) * sizeof(float) +
-                       MAX_T * sizeof(int);
+  const size_t shmem = (size_t)(2 * d + 2 * T + 3 * MAX_E + 8 + 3 * T * E) * sizeof(float) + (size_t)T * sizeof(int);
   hipLaunchKernelGGL(dynexp_scores_kernel, dim3(N), dim3(512), shmem, s, p);
   dim3 grid(N, (d + 127) / 128);
-  const size_t sh2 = (size_t)(4 * T * E) * sizeof(float) + (size_t)T * sizeof(int);
-  switch (E) {
-    case 4: hipLaunchKernelGGL(dynexp_accum_kernel<4>, grid, dim3(128), sh2, s, p); break;
-    case 8: hipLaunchKernelGGL(dynexp_accum_kernel<8>, grid, dim3(128), sh2, s, p); break;
-    case 16: hipLaunchKernelGGL(dynexp_accum_kernel<16>, grid, dim3(128), sh2, s, p); break;
-    default: hipLaunchKernelGGL(dynexp_accum_kernel<32>, grid, dim3(128), sh2, s, p); break;
-  }
+  const size_t sh2 = (size_t)(4 * T + 2 * E) * sizeof(float) + (size_t)T * sizeof(int);
+  hipLaunchKernelGGL(dynexp_accum_kernel, grid, dim3(128), sh2, s, p);
   return odic_launch_status();
 }
 

@@ -407,20 +407,20 @@ def dec_embed(tokens, embed, pos_table, pos, y, ldy, N, d, scale) -> None:
                                               _stream()), "odic_dec_embed")
 
 
-def dynexp_step(lin, ldlin, qexp, bexp, cond_c, key_c, va_c, vb_c, afull_c, bfull_c, qk_c, anc, row_valid, pos,
+def dynexp_step(lin, ldlin, qexp, bexp, cond_c, key_c, va_c, vb_c, wfa_c, wfb_c, qk_c, anc, row_valid, pos,
                 y_in, ldy_in, y, ldy, scratch, N, T, d, E, eps=1e-9) -> None:
-    _need_cuda(lin, qexp, bexp, cond_c, key_c, va_c, vb_c, afull_c, bfull_c, qk_c, anc, row_valid, pos, y_in, y)
-    # algorithmic bytes of one incremental step at position t (layers.py:152-204 on the newest row only):
-    # in  lin [N,5d], y_in; history of positions <= t through the ancestor table: cond, key [d each],
-    #     class_a/b+bias [E·d each], query·key [E];   out  the same cache rows for position t, y.
-    # t = the host's step hint, else the mean position of a T-long search.
+    _need_cuda(lin, qexp, bexp, cond_c, key_c, va_c, vb_c, wfa_c, wfb_c, qk_c, anc, row_valid, pos, y_in, y)
+    # algorithmic bytes of one incremental step at position t (layers.py:152-204 on the newest row only, in the
+    # re-associated form of csrc/decoder_ops.hip): in  lin [N,5d], y_in; through the ancestor table, per earlier
+    # position cond, key, va, vb [d each], its (j+1)·E forward weights (x2) and query·key [E];  out  the position's
+    # cache rows and y.   t = the host's step hint, else the mean position of a T-long search.
     t = _STEP_T if _STEP_T is not None else (T - 1) / 2.0
-    per_pos = (2 * d + 2 * E * d + E) * 4.0
-    nbytes = N * ((5 * d + 2 * d) * 4.0 + (t + 1) * per_pos + per_pos + 2 * d * 4.0 + (t + 1) * 4.0)
-    flops = N * (t + 1) * (2.0 * 2 * d + 2.0 * 2 * E * d + 8.0 * E)
+    nbytes = N * ((5 * d + 2 * d) * 4.0 + (t + 1) * (4 * d + E) * 4.0 + (t + 1) * (t + 2) * E * 4.0
+                  + (4 * d + 2 * (t + 1) * E + E) * 4.0 + (t + 1) * 4.0)
+    flops = N * ((2 * t + E + 1) * 2.0 * d + 6.0 * (t + 1) * d + 2.0 * (t + 1) * (t + 2) * E)
     with _timed("dynexp_step", flops, nbytes):
         _hip.check(_hip.load().odic_dynexp_step(_p(lin), ldlin, _p(qexp), _p(bexp), _p(cond_c), _p(key_c), _p(va_c),
-                                                _p(vb_c), _p(afull_c), _p(bfull_c), _p(qk_c), _p(anc), _p(row_valid),
+                                                _p(vb_c), _p(wfa_c), _p(wfb_c), _p(qk_c), _p(anc), _p(row_valid),
                                                 _p(pos), _p(y_in), ldy_in, _p(y), ldy, _p(scratch), N, T, d, E, eps,
                                                 _stream()),
                    "odic_dynexp_step")

@@ -336,12 +336,12 @@ def test_dynexp_step_matches_full_recompute(ops):
     dv = "cuda"
     Wcat = torch.cat([sd[f"p.{nm}.weight"] for nm in names], 0)
     bcat = torch.cat([sd[f"p.{nm}.bias"] for nm in names], 0)
-    caches = [torch.zeros(T, N, d, device=dv) for _ in range(4)] + [torch.zeros(T, N, E, d, device=dv) for _ in range(2)]
+    caches = [torch.zeros(T, N, d, device=dv) for _ in range(4)] + [torch.zeros(T, N, T, E, device=dv) for _ in range(2)]
     qk = torch.zeros(T, N, E, device=dv)
     anc = torch.arange(N, dtype=torch.int32, device=dv)[:, None].repeat(1, T).contiguous()
     pos = torch.zeros(1, dtype=torch.int32, device=dv)
     got = torch.empty(N, T, d)
-    scratch = torch.zeros(N, 4 * T * E + T, device=dv)
+    scratch = torch.zeros(N, 5 * T + 2 * E, device=dv)
     for step in range(T):
         pos.fill_(step)
         xs = dev(x[:, step].contiguous())
