@@ -69,8 +69,10 @@ __device__ __forceinline__ int wperm(int r) {
 
 // LNF: 0 plain, 1 producer of a folded LayerNorm (fp32 out + bf16 copy + row-group moments), 2 consumer
 // (separate instantiations: the extra registers of the fold must not cost the plain products their occupancy)
+// (second launch bound: the 4-wave blocks with 128 accumulator registers per lane must stay within 256 registers
+//  so that two of them share a CU — left alone hipcc takes 158 + 128)
 template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK, typename OutT, int LNF = 0>
-__global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_nt_kernel(Params p) {
+__global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && MI * NI == 32) ? 2 : 1) void gemm_bf16_nt_kernel(Params p) {
   constexpr int NW = NWM * NWN;
   constexpr int ROWB = BK * 2;                 // bytes per LDS row
   constexpr int RPI = 1024 / ROWB;             // rows per 1-KiB DMA instruction
@@ -993,6 +995,11 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     case 13: return launch_cfg<4, 4, 4, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32, 16 waves of 64 x 64, 3 stages (96 KiB)
     case 14: return launch_cfg<4, 4, 4, 4, 2, 64>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 64, 16 waves of 64 x 64, 2 stages (128 KiB)
     case 15: return launch_cfg<4, 4, 4, 4, 4, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32, 16 waves, 4 stages (128 KiB)
+    // 4 waves of 128 x 64 (64 x 128): 12 KiB of LDS reads per 32 MFMAs instead of 8 KiB per 16, two blocks per CU
+    case 28: return launch_cfg<2, 2, 8, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32, 3 stages (72 KiB)
+    case 29: return launch_cfg<2, 2, 4, 8, 3, 32>(p, a->out_dtype, a->batch, stream); // 128 x 256 x 32, 3 stages (72 KiB)
+    case 30: return launch_cfg<2, 2, 8, 4, 2, 32>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32, 2 stages (48 KiB)
+    case 31: return launch_cfg<2, 2, 8, 4, 2, 64>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 64, 2 stages (96 KiB)
     case 12: if (p.out16 || p.ln_stats) return ODIC_EUNSUPPORTED;
              return launch_256sq(p, a->out_dtype, a->batch, stream);                 // 256 x 256 x 64, 4 phases per K-tile (128 KiB)
     // 16 + c: tile config c as a persistent, dynamically scheduled launch (needs args->workspace, batch == 1)

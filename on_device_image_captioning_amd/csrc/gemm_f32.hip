@@ -145,8 +145,17 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(Params p) {
 // so the product runs on the RAW rows and only the epilogue needs the row moments — which every
 // wave accumulates for free from the A fragments it loads anyway (Σa, Σa² over its K-slice).
 // ---------------------------------------------------------------------------------------------
-template <int MTW, int UN, bool FOLD, typename OutT>
-__global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int kslice, int KS, int MT) {
+//
+// Decomposition (launch_skinny): grid = (N/16 column tiles) x (row blocks); a block owns MT row tiles starting at
+// tile blockIdx.y·MT.  Three shapes of it are built (odic_gemm_args.tile_cfg 0 / 1 / 2, -1 = by block count):
+//   0  all rows in one block, waves = K-slices x row tiles (<= 16 waves, K-slices of >= 64)           [round 1]
+//   1  one row tile per block (grid.y = MT): waves = min(16, K/64) K-slices, each wave ONE round trip of loads at
+//      K = 512 and two at K = 2048 — the fp32 MFMA work of a launch (157 TFLOP/s chip-wide = 0.6 per CU) spreads
+//      over 3x the CUs and the per-wave chain of dependent load rounds shrinks 3x (48x512x2048: 24 -> 11 us);
+//   2  three row tiles per WAVE (W fragments loaded once per block, 8 K-slices, 512-thread blocks that fit four to a
+//      CU): for the wide products (vocabulary, 625 column tiles) where shape 1 would be thousands of blocks.
+template <int MTW, int UN, bool FOLD, typename OutT, int MAXT>
+__global__ __launch_bounds__(MAXT) void gemm_f32_skinny_kernel(Params p, int kslice, int KS, int MT) {
   extern __shared__ float red[];                   // [KS][MT][4][64] partial tiles (+ [KS][MT*16][2] row sums if FOLD)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,7 +166,8 @@ __global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int ksl
   const float* W = p.W + bz * p.strideW;
   const int fr = lane & 15, fq = lane >> 4;
   const int k_begin = ks * kslice, k_end = min(p.K, k_begin + kslice);
-  const int t0 = ms * MTW;                          // first row tile of this wave
+  const int t0 = ms * MTW;                          // first row tile of this wave (block-local)
+  const int tb = blockIdx.y * MT;                   // first row tile of this block
 
   f32x4_t acc[MTW];
   float sx[MTW], sxx[MTW];
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int ksl
   bool am_ok[MTW];
 #pragma unroll
   for (int i = 0; i < MTW; ++i) {
-    const int m = (t0 + i) * 16 + fr;
+    const int m = (tb + t0 + i) * 16 + fr;
     am_ok[i] = m < p.M;
     arow[i] = A + (long)min(m, p.M - 1) * p.lda + 4 * fq;
   }
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int ksl
     float v = 0.f;
     for (int w = 0; w < KS; ++w) v += red[((w * MT + i) * 4 + j) * 64 + l];
     const int r16 = (l >> 4) * 4 + j;
-    const int row = i * 16 + r16, col = n0 + (l & 15);
+    const int row = (tb + i) * 16 + r16, col = n0 + (l & 15);
     if (row < p.M && col < p.N) {
       v *= p.alpha;
       if constexpr (FOLD) {
@@ -266,25 +276,27 @@ __global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(Params p, int ksl
   }
 }
 
-template <int MTW, int UN>
-static void launch_skinny(const Params& p, int out_dtype, int batch, hipStream_t stream) {
-  const int MT = (p.M + 15) / 16;
+template <int MTW, int UN, int MAXW>
+static void launch_skinny(const Params& p, int out_dtype, int batch, hipStream_t stream, int row_blocks, int lds_kib) {
+  const int MT_all = (p.M + 15) / 16;
+  const int MT = (MT_all + row_blocks - 1) / row_blocks;             // row tiles per block
   const int MS = (MT + MTW - 1) / MTW;
-  // K-slices of >= 64, KS·MS <= 16 waves, KS·MT KiB of LDS for the partial tiles <= ODIC_SKINNY_LDS_KIB
+  // K-slices of >= 64, KS·MS <= MAXW waves, KS·MT KiB of LDS for the partial tiles <= lds_kib
   int KS = (p.K + 63) / 64;
-  if (KS > 16 / MS) KS = 16 / MS;
-  while (KS > 1 && KS * MT > ODIC_SKINNY_LDS_KIB) --KS;
+  if (KS > MAXW / MS) KS = MAXW / MS;
+  while (KS > 1 && KS * MT > lds_kib) --KS;
   if (KS < 1) KS = 1;
   const int kslice = ((p.K + KS - 1) / KS + 15) / 16 * 16;
-  dim3 grid((p.N + 15) / 16, 1, batch), block(64 * KS * MS);
+  dim3 grid((p.N + 15) / 16, (MT_all + MT - 1) / MT, batch), block(64 * KS * MS);
   const size_t shmem = (size_t)(KS * MT * 256 + KS * MT * 32) * sizeof(float);
   const bool fold = p.ln_colsum != nullptr;
+  constexpr int MAXT = 64 * MAXW;
   if (out_dtype == ODIC_BF16) {
-    if (fold) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, true, bf16_raw>), grid, block, shmem, stream, p, kslice, KS, MT);
-    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, false, bf16_raw>), grid, block, shmem, stream, p, kslice, KS, MT);
+    if (fold) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, true, bf16_raw, MAXT>), grid, block, shmem, stream, p, kslice, KS, MT);
+    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, false, bf16_raw, MAXT>), grid, block, shmem, stream, p, kslice, KS, MT);
   } else {
-    if (fold) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, true, float>), grid, block, shmem, stream, p, kslice, KS, MT);
-    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, false, float>), grid, block, shmem, stream, p, kslice, KS, MT);
+    if (fold) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, true, float, MAXT>), grid, block, shmem, stream, p, kslice, KS, MT);
+    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, false, float, MAXT>), grid, block, shmem, stream, p, kslice, KS, MT);
   }
 }
 
@@ -305,11 +317,19 @@ int odic_gemm_f32_launch(const odic_gemm_args* a, hipStream_t stream) {
   const bool skinny_ok = p.vec_ok && a->M <= 192 && a->K % 16 == 0;
   if (want_ln && !(skinny_ok && a->bias_axis == 0)) return ODIC_EUNSUPPORTED;
   if (skinny_ok && (a->N >= 64 || want_ln)) {
-    const int mt = (a->M + 15) / 16;
-    // (MTW, UN): two rounds of UN·(1 + MTW) float4 per lane are in flight — 64 / 48 / 64 registers
-    if (mt <= 4) launch_skinny<1, 4>(p, a->out_dtype, a->batch, stream);        // one row tile per wave
-    else if (mt <= 8) launch_skinny<2, 2>(p, a->out_dtype, a->batch, stream);
-    else launch_skinny<3, 2>(p, a->out_dtype, a->batch, stream);
+    const int mt = (a->M + 15) / 16, ct = (a->N + 15) / 16;
+    int shape = a->tile_cfg;
+    if (shape < 0 || shape > 2) shape = (long)ct * mt * a->batch <= 768 ? 1 : 2;
+    if (shape == 1) {
+      launch_skinny<1, 4, 16>(p, a->out_dtype, a->batch, stream, mt, 16);
+    } else if (shape == 2) {
+      launch_skinny<3, 4, 8>(p, a->out_dtype, a->batch, stream, (mt + 2) / 3, 24);
+    } else {
+      // (MTW, UN): two rounds of UN·(1 + MTW) float4 per lane are in flight — 64 / 48 / 64 registers
+      if (mt <= 4) launch_skinny<1, 4, 16>(p, a->out_dtype, a->batch, stream, 1, ODIC_SKINNY_LDS_KIB);   // one row tile per wave
+      else if (mt <= 8) launch_skinny<2, 2, 16>(p, a->out_dtype, a->batch, stream, 1, ODIC_SKINNY_LDS_KIB);
+      else launch_skinny<3, 2, 16>(p, a->out_dtype, a->batch, stream, 1, ODIC_SKINNY_LDS_KIB);
+    }
     return odic_launch_status();
   }
   dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM, a->batch);

@@ -79,9 +79,10 @@ def test_gemm_f32_row_bias_strided_batched(ops):
     assert torch.all(got[:, :, N:] == 7.0), "padding columns must stay untouched"
 
 
+@pytest.mark.parametrize("shape", [-1, 0, 1, 2])
 @pytest.mark.parametrize("M,N,K,act", [(48, 200, 512, 0), (48, 2048, 512, 2), (144, 512, 512, 0), (17, 100, 64, 0),
                                        (100, 1000, 512, 0)])
-def test_gemm_f32_folded_layernorm(ops, M, N, K, act):
+def test_gemm_f32_folded_layernorm(ops, M, N, K, act, shape):
     # LayerNorm(A)·Wᵀ + b with A a strided slice of a wider buffer (the decoder's residual-stream layout),
     # LayerNorm folded into the product: W·diag(gamma), bias + W·beta, row sums (ops.fold_layernorm)
     lda = 3 * K
@@ -93,7 +94,8 @@ def test_gemm_f32_folded_layernorm(ops, M, N, K, act):
         want = torch.relu(want)
     Wf, bf, cs = ops.fold_layernorm(dev(Wt), dev(b), dev(g), dev(be))
     dbuf = dev(buf)
-    got = ops.gemm(dbuf[:, K:], Wf, bf, M=M, N=N, K=K, lda=lda, ldw=K, ldc=N, act=act, ln_fold=(cs, 1e-5))
+    got = ops.gemm(dbuf[:, K:], Wf, bf, M=M, N=N, K=K, lda=lda, ldw=K, ldc=N, act=act, ln_fold=(cs, 1e-5),
+                   tile_cfg=shape)
     assert_close(got, want, 3e-5, "folded LN gemm")
 
 
@@ -103,12 +105,15 @@ def test_gemm_f32_folded_layernorm_rejects_wide_M(ops):
         ops.gemm(dev(rnd(400, 64, seed=1)), Wf, bf, ln_fold=(cs, 1e-5))
 
 
-@pytest.mark.parametrize("M,N,K", [(48, 512, 2048), (48, 512, 1536), (96, 512, 512), (150, 10000, 512), (192, 64, 4096)])
-def test_gemm_f32_skinny_wave_splits(ops, M, N, K):
-    # K-slices x row-tile groups across the waves of a block, with residual + relu epilogue
+@pytest.mark.parametrize("shape", [-1, 0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(48, 512, 2048), (48, 512, 1536), (96, 512, 512), (150, 10000, 512), (192, 64, 4096),
+                                   (40, 10000, 512), (3, 512, 80)])
+def test_gemm_f32_skinny_wave_splits(ops, M, N, K, shape):
+    # the three decompositions of the skinny kernel (K-slices x row tiles over waves / one row tile per block /
+    # three row tiles per wave), with residual + relu epilogue
     A, Wt, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
     want = torch.relu(A.double() @ Wt.double().T + b.double()) + r.double()
-    got = ops.gemm(dev(A), dev(Wt), dev(b), dev(r), act=2)
+    got = ops.gemm(dev(A), dev(Wt), dev(b), dev(r), act=2, tile_cfg=shape)
     assert_close(got, want, 2e-5, "gemm_f32 skinny")
 
 
@@ -376,7 +381,7 @@ def test_gemm_bf16_256sq_phase_pipeline(ops):
 PERSISTENT_CFGS = [16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27]
 
 
-@pytest.mark.parametrize("cfg", list(range(12)) + [13, 14, 15] + PERSISTENT_CFGS)
+@pytest.mark.parametrize("cfg", list(range(12)) + [13, 14, 15, 28, 29, 30, 31] + PERSISTENT_CFGS)
 def test_gemm_bf16_every_tile_config(ops, cfg):
     """Each tile / pipeline-depth / BK instantiation — one block per tile (0..11) and persistent with dynamic tile
     scheduling (16 + c) — against fp64 on ragged shapes (M, N not multiples of any tile) with every epilogue

@@ -19,8 +19,11 @@ for N, K in ((512, 512), (2560, 512), (2048, 512), (512, 2048), (512, 1536), (10
     out = torch.empty(M, N, device="cuda")
     Wf, bf, cs = ops.fold_layernorm(W, b, torch.ones(K, device="cuda"), torch.zeros(K, device="cuda"))
     cells = []
-    for name, fn in (("plain", lambda: ops.gemm(A, W, b, out=out)),
-                     ("folded-LN", lambda: ops.gemm(A, Wf, bf, out=out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, ln_fold=(cs, 1e-5)))):
+    variants = []
+    for shp in (0, 1, 2):
+        variants.append((f"shape{shp}", lambda shp=shp: ops.gemm(A, W, b, out=out, tile_cfg=shp)))
+    variants.append(("auto folded-LN", lambda: ops.gemm(A, Wf, bf, out=out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, ln_fold=(cs, 1e-5))))
+    for name, fn in variants:
         with torch.cuda.stream(s):
             fn()
         torch.cuda.synchronize()
@@ -38,5 +41,5 @@ for N, K in ((512, 512), (2560, 512), (2048, 512), (512, 2048), (512, 1536), (10
             en.record()
         torch.cuda.synchronize()
         us = st.elapsed_time(en) * 1e3 / (5 * 64)
-        cells.append(f"{name} {us:6.2f} us ({N * K * 4 / us / 1e3:6.1f} GB/s)")
+        cells.append(f"{name} {us:6.2f} us")
     print(f"M={M} N={N:5d} K={K:4d} | " + " | ".join(cells))
