@@ -226,14 +226,13 @@ int odic_dec_embed(const int64_t* tokens, const float* embed, const float* pos_t
  *   row_valid int32 [N]: 0 → padded row (finished beam): the block contributes 0 (masked rows of
  *        utils/masking.py:37-47), caches are still written.
  *   y_in fp32 [N,d] (ldy_in) → y fp32 [N,d] (ldy):  y = y_in + sel·A' + (1-sel)·B'  (may alias).
- *   scratch fp32 [N, 5·T + 2·E]: coefficient vectors handed from the score kernel to the accumulation
- *        kernel.   T <= 128, E in {4, 8, 16, 32}.
+ *   T <= 128, E in {4, 8, 16, 32}, d a multiple of 64; one launch (one 512-thread block per sequence).
  */
 int odic_dynexp_step(const float* lin, int64_t ldlin, const float* qexp, const float* bexp,
                      float* cond_c, float* key_c, float* va_c, float* vb_c, float* wfa_c,
                      float* wfb_c, float* qk_c, const int32_t* anc, const int32_t* row_valid,
                      const int32_t* pos, const float* y_in, int64_t ldy_in, float* y, int64_t ldy,
-                     float* scratch, int32_t N, int32_t T, int32_t d, int32_t E, float eps, void* stream);
+                     int32_t N, int32_t T, int32_t d, int32_t E, float eps, void* stream);
 
 /* Cross attention of one query row per sequence against per-IMAGE cached K/V (layers.py:266-295;
  * the reference re-projects K/V of the 144 encoder tokens every step for every beam copy).

@@ -57,7 +57,7 @@ _SIGNATURES = {
     "odic_stcexp_normalize": (C.c_int, [_P, _P, _P, _I32, _P, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _I32, _P]),
     "odic_selector_mix": (C.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _P]),
     "odic_dec_embed": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
-    "odic_dynexp_step": (C.c_int, [_P, _I64, _P, _P] + [_P] * 7 + [_P, _P, _P, _P, _I64, _P, _I64, _P] + [_I32] * 4 + [_F, _P]),
+    "odic_dynexp_step": (C.c_int, [_P, _I64, _P, _P] + [_P] * 7 + [_P, _P, _P, _P, _I64, _P, _I64] + [_I32] * 4 + [_F, _P]),
     "odic_cross_attn_step": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P, _P, _P, _I64] + [_I32] * 5 + [_P]),
     "odic_logsoftmax_topk": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _P]),
     "odic_logsoftmax_sample": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, C.c_uint64, _P, _P]),

@@ -76,17 +76,14 @@ struct DynParams {
   const float* lin; long ldlin; const float* qexp; const float* bexp;
   float* cond_c; float* key_c; float* va_c; float* vb_c; float* wfa_c; float* wfb_c; float* qk_c;
   const int* anc; const int* row_valid; const int* pos; const float* y_in; long ldyi; float* y; long ldy;
-  float* scratch;                 // [N][5*T + 2*E floats]
   int N, T, d, E; float eps;
 };
 
-// scratch layout per sequence (floats): ca[T] | cb[T] | wja[T] | wjb[T] | wea[E] | web[E] | slot[T] (int)
-__device__ __forceinline__ long dyn_scratch_stride(int T, int E) { return 5L * T + 2L * E; }
-
-// Kernel 1 (one block per sequence, 512 threads): cache writes, the 2t+E+1 dot products (one per 16-lane group,
+// One block per sequence, 512 threads.  Phase 1: cache writes, the 2t+E+1 dot products (one per 16-lane group,
 // 32 in flight per block, float4 loads), the normalised forward / backward weights, and the coefficients of
-// the re-associated sum → scratch.
-__global__ __launch_bounds__(512) void dynexp_scores_kernel(DynParams p) {
+// the re-associated sum → LDS.  Phase 2 (one channel per thread): the sums over the cached value, condition and
+// bias rows — 3·(t+1) + E independent, coalesced loads per thread.
+__global__ __launch_bounds__(512) void dynexp_step_kernel(DynParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int d = p.d, E = p.E, T = p.T, n = blockIdx.x, tid = threadIdx.x;
   const int t = *p.pos;
@@ -101,11 +98,11 @@ __global__ __launch_bounds__(512) void dynexp_scores_kernel(DynParams p) {
   float* qkh = (float*)(slot + T);     // [T*E]  qexp[e]·key_j history
   float* wba = qkh + T * E;            // [T*E]  backward weights of this step
   float* wbb = wba + T * E;            // [T*E]
+  float* scr = wbb + T * E;            // ca[T] | cb[T] | wja[T] | wjb[T] | wea[E] | web[E]
 
   const float* lin = p.lin + (long)n * p.ldlin;
   const float inv_sqrt_d = rsqrtf((float)d);
   const long NT = (long)p.N;
-  float* scr = p.scratch + (long)n * dyn_scratch_stride(T, E);
   const int TE = T * E;
 
   for (int c = tid; c < d; c += 512) {
@@ -117,7 +114,6 @@ __global__ __launch_bounds__(512) void dynexp_scores_kernel(DynParams p) {
   for (int j = tid; j <= t; j += 512) {
     const int sl = j < t ? p.anc[(long)n * T + j] : n;
     slot[j] = sl;
-    ((int*)(scr + 4 * T + 2 * E))[j] = sl;
   }
   __syncthreads();
   for (int i = tid; i < t * E; i += 512) {
@@ -222,51 +218,37 @@ __global__ __launch_bounds__(512) void dynexp_scores_kernel(DynParams p) {
     for (int j = 0; j <= t; ++j) { sa += wba[j * E + e]; sb += wbb[j * E + e]; }
     scr[4 * T + e] = sa; scr[4 * T + E + e] = sb;
   }
-}
-
-// Kernel 2 (grid N x d/128, 128 threads, one channel per thread): the re-associated sums over the cached value,
-// condition and bias rows.  3·(t+1) + E independent, coalesced loads per thread.
-__global__ __launch_bounds__(128) void dynexp_accum_kernel(DynParams p) {
-  extern __shared__ float w[];             // ca | cb | wja | wjb [T each] | wea | web [E each] | slot [T]
-  const int T = p.T, E = p.E;
-  const int d = p.d, n = blockIdx.x, tid = threadIdx.x;
-  const int c = blockIdx.y * 128 + tid;
-  const int t = *p.pos;
-  const long NT = (long)p.N;
-  const float* scr = p.scratch + (long)n * dyn_scratch_stride(T, E);
-  const int nw = 4 * T + 2 * E;
-  for (int i = tid; i < nw; i += 128) w[i] = scr[i];
-  int* slot = (int*)(w + nw);
-  for (int j = tid; j <= t; j += 128) slot[j] = ((const int*)(scr + nw))[j];
   __syncthreads();
-  if (c >= d) return;
-  const float* ca = w; const float* cb = w + T;
-  const float* wja = w + 2 * T; const float* wjb = w + 3 * T;
-  const float* wea = w + 4 * T; const float* web = wea + E;
-  const float* lin = p.lin + (long)n * p.ldlin;
 
-  float oa = 0.f, ob = 0.f;
+  // ---- phase 2
+  const float* ca = scr; const float* cb = scr + T;
+  const float* wja = scr + 2 * T; const float* wjb = scr + 3 * T;
+  const float* wea = scr + 4 * T; const float* web = wea + E;
+  const bool valid = p.row_valid[n] != 0;
+  for (int c = tid; c < d; c += 512) {
+    float oa = 0.f, ob = 0.f;
 #pragma unroll 4
-  for (int j = 0; j <= t; ++j) {
-    const long o = ((long)j * NT + slot[j]) * d + c;
-    const float va = j < t ? p.va_c[o] : lin[2 * d + c];
-    const float vb = j < t ? p.vb_c[o] : lin[3 * d + c];
-    const float cj = j < t ? p.cond_c[o] : lin[c];
-    oa = fmaf(ca[j], va, oa); oa = fmaf(wja[j], cj, oa);
-    ob = fmaf(cb[j], vb, ob); ob = fmaf(wjb[j], cj, ob);
-  }
+    for (int j = 0; j < t; ++j) {
+      const long o = ((long)j * NT + slot[j]) * d + c;
+      const float va = p.va_c[o], vb = p.vb_c[o], cj = p.cond_c[o];
+      oa = fmaf(ca[j], va, oa); oa = fmaf(wja[j], cj, oa);
+      ob = fmaf(cb[j], vb, ob); ob = fmaf(wjb[j], cj, ob);
+    }
+    oa = fmaf(ca[t], lin[2 * d + c], oa); oa = fmaf(wja[t], cond_t[c], oa);
+    ob = fmaf(cb[t], lin[3 * d + c], ob); ob = fmaf(wjb[t], cond_t[c], ob);
 #pragma unroll 4
-  for (int e = 0; e < E; ++e) {
-    const float be = p.bexp[(long)e * d + c];
-    oa = fmaf(wea[e], be, oa);
-    ob = fmaf(web[e], be, ob);
+    for (int e = 0; e < E; ++e) {
+      const float be = p.bexp[(long)e * d + c];
+      oa = fmaf(wea[e], be, oa);
+      ob = fmaf(web[e], be, ob);
+    }
+    float yv = p.y_in[(long)n * p.ldyi + c];
+    if (valid) {
+      const float sg = 1.0f / (1.0f + expf(-lin[4 * d + c]));
+      yv += sg * oa + (1.0f - sg) * ob;
+    }
+    p.y[(long)n * p.ldy + c] = yv;
   }
-  float yv = p.y_in[(long)n * p.ldyi + c];
-  if (p.row_valid[n]) {
-    const float sg = 1.0f / (1.0f + expf(-lin[4 * d + c]));
-    yv += sg * oa + (1.0f - sg) * ob;
-  }
-  p.y[(long)n * p.ldy + c] = yv;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -601,6 +583,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamParams p) {
   const int lane = threadIdx.x, b = blockIdx.x;
   const int k = p.k, T = p.T;
   const int t = *p.pos;                 // position just processed; prefix length is t+1
+  if (t + 1 >= T) return;               // the prefix is full: a replay past the last step changes nothing
   int alive_any = 0;
 
   // everything lane 0's serial selection touches is first brought into LDS by all 64 lanes
@@ -772,24 +755,22 @@ extern "C" int odic_dynexp_step(const float* lin, int64_t ldlin, const float* qe
                                 float* cond_c, float* key_c, float* va_c, float* vb_c, float* wfa_c,
                                 float* wfb_c, float* qk_c, const int32_t* anc, const int32_t* row_valid,
                                 const int32_t* pos, const float* y_in, int64_t ldy_in, float* y, int64_t ldy,
-                                float* scratch, int32_t N, int32_t T, int32_t d, int32_t E, float eps, void* stream) {
+                                int32_t N, int32_t T, int32_t d, int32_t E, float eps, void* stream) {
   if (!lin || !qexp || !bexp || !cond_c || !key_c || !va_c || !vb_c || !wfa_c || !wfb_c || !qk_c || !anc ||
-      !row_valid || !pos || !y || !y_in || !scratch)
+      !row_valid || !pos || !y || !y_in)
     return ODIC_ENULL;
   if (N <= 0 || T <= 0 || T > MAX_T || d <= 0 || E <= 0 || E > MAX_E) return ODIC_EINVAL;
   if (E != 4 && E != 8 && E != 16 && E != 32) return ODIC_EUNSUPPORTED;
+  if (d % 64) return ODIC_EINVAL;
   DynParams p;
   p.lin = lin; p.ldlin = ldlin; p.qexp = qexp; p.bexp = bexp; p.cond_c = cond_c; p.key_c = key_c; p.va_c = va_c;
   p.vb_c = vb_c; p.wfa_c = wfa_c; p.wfb_c = wfb_c; p.qk_c = qk_c; p.anc = anc; p.row_valid = row_valid;
-  p.pos = pos; p.y_in = y_in; p.ldyi = ldy_in; p.y = y; p.ldy = ldy; p.scratch = scratch;
+  p.pos = pos; p.y_in = y_in; p.ldyi = ldy_in; p.y = y; p.ldy = ldy;
   p.N = N; p.T = T; p.d = d; p.E = E; p.eps = eps;
-  hipStream_t s = (hipStream_t)stream;
-  if (d % 64) return ODIC_EINVAL;
-  const size_t shmem = (size_t)(2 * d + 2 * T + 3 * MAX_E + 8 + 3 * T * E) * sizeof(float) + (size_t)T * sizeof(int);
-  hipLaunchKernelGGL(dynexp_scores_kernel, dim3(N), dim3(512), shmem, s, p);
-  dim3 grid(N, (d + 127) / 128);
-  const size_t sh2 = (size_t)(4 * T + 2 * E) * sizeof(float) + (size_t)T * sizeof(int);
-  hipLaunchKernelGGL(dynexp_accum_kernel, grid, dim3(128), sh2, s, p);
+  const size_t shmem = (size_t)(2 * d + 2 * T + 3 * MAX_E + 8 + 3 * T * E + 4 * T + 2 * E) * sizeof(float) +
+                       (size_t)T * sizeof(int);
+  if (shmem > 64 * 1024) return ODIC_EINVAL;
+  hipLaunchKernelGGL(dynexp_step_kernel, dim3(N), dim3(512), shmem, (hipStream_t)stream, p);
   return odic_launch_status();
 }
 

@@ -223,7 +223,6 @@ class DecodeState:
         self.caches = [dict(cond=f(T, N, d), key=f(T, N, d), va=f(T, N, d), vb=f(T, N, d),
                             wfa=f(T, N, T, E), wfb=f(T, N, T, E), qk=f(T, N, E)) for _ in range(L)]
         self.anc = i32(N, T)
-        self.dyn_scratch = f(N, 5 * T + 2 * E)
         self.row_valid = torch.ones(N, dtype=torch.int32, device=dv)
         self.next_tok = torch.zeros(N, dtype=torch.int64, device=dv)
         self.pos, self.done, self.ctr = i32(1), i32(1), i32(1)
@@ -418,7 +417,7 @@ class CaptionerEngine:
             xo = st.ycat[:, i * d:]
             lin = ln_gemm(xin, ld, w["n1w"], w["n1b"], w["dyn_w"], w["dyn_b"], w["dyn_f"])               # [N,5d]
             ops.dynexp_step(lin, 5 * d, w["qexp"], w["bexp"], c["cond"], c["key"], c["va"], c["vb"], c["wfa"],
-                            c["wfb"], c["qk"], st.anc, st.row_valid, st.pos, xin, ld, xo, ld, st.dyn_scratch, N, st.T, d,
+                            c["wfb"], c["qk"], st.anc, st.row_valid, st.pos, xin, ld, xo, ld, N, st.T, d,
                             g.num_exp_dec)
             q = ln_gemm(xo, ld, w["n2w"], w["n2b"], w["wq"], w["bq"], w["wq_f"])
             att = torch.empty(N, d, dtype=torch.float32, device=self.device)

@@ -408,7 +408,7 @@ def dec_embed(tokens, embed, pos_table, pos, y, ldy, N, d, scale) -> None:
 
 
 def dynexp_step(lin, ldlin, qexp, bexp, cond_c, key_c, va_c, vb_c, wfa_c, wfb_c, qk_c, anc, row_valid, pos,
-                y_in, ldy_in, y, ldy, scratch, N, T, d, E, eps=1e-9) -> None:
+                y_in, ldy_in, y, ldy, N, T, d, E, eps=1e-9) -> None:
     _need_cuda(lin, qexp, bexp, cond_c, key_c, va_c, vb_c, wfa_c, wfb_c, qk_c, anc, row_valid, pos, y_in, y)
     # algorithmic bytes of one incremental step at position t (layers.py:152-204 on the newest row only, in the
     # re-associated form of csrc/decoder_ops.hip): in  lin [N,5d], y_in; through the ancestor table, per earlier
@@ -421,7 +421,7 @@ def dynexp_step(lin, ldlin, qexp, bexp, cond_c, key_c, va_c, vb_c, wfa_c, wfb_c,
     with _timed("dynexp_step", flops, nbytes):
         _hip.check(_hip.load().odic_dynexp_step(_p(lin), ldlin, _p(qexp), _p(bexp), _p(cond_c), _p(key_c), _p(va_c),
                                                 _p(vb_c), _p(wfa_c), _p(wfb_c), _p(qk_c), _p(anc), _p(row_valid),
-                                                _p(pos), _p(y_in), ldy_in, _p(y), ldy, _p(scratch), N, T, d, E, eps,
+                                                _p(pos), _p(y_in), ldy_in, _p(y), ldy, N, T, d, E, eps,
                                                 _stream()),
                    "odic_dynexp_step")
 

@@ -346,7 +346,6 @@ def test_dynexp_step_matches_full_recompute(ops):
     anc = torch.arange(N, dtype=torch.int32, device=dv)[:, None].repeat(1, T).contiguous()
     pos = torch.zeros(1, dtype=torch.int32, device=dv)
     got = torch.empty(N, T, d)
-    scratch = torch.zeros(N, 5 * T + 2 * E, device=dv)
     for step in range(T):
         pos.fill_(step)
         xs = dev(x[:, step].contiguous())
@@ -354,7 +353,7 @@ def test_dynexp_step_matches_full_recompute(ops):
         y = torch.zeros(N, d, device=dv)
         valid = dev(ok[:, step].to(torch.int32))
         ops.dynexp_step(lin, 5 * d, dev(sd["p.query_exp_vectors.weight"]), dev(sd["p.bias_exp_vectors.weight"]),
-                        *caches, qk, anc, valid, pos, y, d, y, d, scratch, N, T, d, E)
+                        *caches, qk, anc, valid, pos, y, d, y, d, N, T, d, E)
         got[:, step] = y.cpu()
     assert_close(got, want, 5e-5, "dynexp_step")
 

@@ -35,8 +35,7 @@ def run():
     with torch.cuda.stream(pipe.s_dec[0]):
         for _ in range(n):
             pipe._reset(0)
-            for _ in range(pipe.steps):
-                pipe.g_step[0].replay()
+            pipe.replay_search(0)
     torch.cuda.synchronize()
 
 

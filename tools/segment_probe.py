@@ -69,10 +69,9 @@ def time_seg(gr, n, with_decode, keep_src=None):
     if with_decode:
         for l in range(2):
             with torch.cuda.stream(pipe.s_dec[l]):
-                for i in range(8 * pipe.steps):
-                    if i % pipe.steps == 0:
-                        pipe._reset(l)
-                    pipe.g_step[l].replay()
+                for i in range(8):
+                    pipe._reset(l)
+                    pipe.replay_search(l)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(s_enc):
         e0.record()

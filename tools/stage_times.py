@@ -40,8 +40,7 @@ def enc():
 def dec():
     with torch.cuda.stream(pipe.s_dec[0]):
         pipe._reset(0)
-        for _ in range(pipe.steps):
-            pipe.g_step[0].replay()
+        pipe.replay_search(0)
 
 
 def both():
@@ -63,7 +62,7 @@ def interference(n_enc=12):
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     lane_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(D)]
-    nsteps = 12 * pipe.steps
+    nsteps = 12
     for l in range(D):
         with torch.cuda.stream(pipe.s_dec[l]):
             pipe._reset(l)
@@ -77,9 +76,8 @@ def interference(n_enc=12):
         if i < nsteps:
             for l in range(D):
                 with torch.cuda.stream(pipe.s_dec[l]):
-                    if i % pipe.steps == 0:
-                        pipe._reset(l)
-                    pipe.g_step[l].replay()
+                    pipe._reset(l)
+                    pipe.replay_search(l)
     with torch.cuda.stream(pipe.s_enc):
         ev1.record()
     for l in range(D):
