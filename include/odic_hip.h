@@ -287,16 +287,32 @@ typedef struct odic_beam_state {
   int32_t* pos; int32_t* done;
   int32_t* ctr;      /* int32 scalar, zero before the first call: inter-block arrival counter */
 } odic_beam_state;
+/* Optional tail of the launch that chooses the next words: the decoder input of the next position,
+ *   y[n] = embed[word_n]·scale + pos_table[pos + 1]   (EmbeddingLayer, layers.py:118-121 — what odic_dec_embed does in
+ * a launch of its own), written while pos + 1 <= T - 2 (the last prefix position is never fed back);
+ * embed fp32 [V, d], pos_table fp32 [>= T - 1, d], y fp32 [n_img·beams, d] (ldy). */
+typedef struct odic_embed_args {
+  const float* embed; const float* pos_table; float* y; int64_t ldy; int32_t d; float scale;
+} odic_embed_args;
 /*   Limits: beams <= 16, 2 <= T <= 128 (per-token log-probs are staged in LDS), n_img <= 32767 (the
- *   arrival counter packs {arrivals, still-growing images} into one int32): ODIC_EINVAL otherwise. */
+ *   arrival counter packs {arrivals, still-growing images} into one int32): ODIC_EINVAL otherwise.
+ *   A call with *pos == T - 1 (the prefix is full) changes nothing.  emb: NULL or the embedding tail above. */
 int odic_beam_step(const float* cand_val, const int32_t* cand_idx, const odic_beam_state* st,
-                   int32_t n_img, int32_t beams, int32_t T, int64_t eos_idx, void* stream);
+                   const odic_embed_args* emb, int32_t n_img, int32_t beams, int32_t T, int64_t eos_idx,
+                   void* stream);
+
+/* The tail of a single-model search step in ONE launch (captioning_model.py:150-223): log_softmax of the step's
+ * logits rows (fp32 [n_img·beams, V], ldl), their `beams` best words (ties → lower index), odic_beam_step on those
+ * candidates (which never leave LDS) and, with emb, the next position's input.  Same limits as odic_beam_step. */
+int odic_beam_search_step(const float* logits, int64_t ldl, int32_t V, const odic_beam_state* st,
+                          const odic_embed_args* emb, int32_t n_img, int32_t beams, int32_t T, int64_t eos_idx,
+                          void* stream);
 
 /* Initial state of a search (captioning_model.py:117-125): tokens[:, :, 0] = sos, logprobs[:, :, 0] = 0,
- * next_tok = sos, row_valid = 1, *pos = *done = *ctr = 0.  One launch instead of six fills on the
- * latency-bound decode stream. */
-int odic_beam_reset(const odic_beam_state* st, int32_t n_img, int32_t beams, int32_t T, int64_t sos_idx,
-                    void* stream);
+ * next_tok = sos, row_valid = 1, *pos = *done = *ctr = 0; with emb, also the input of position 0 (the embedded
+ * start token).  One launch instead of six fills on the latency-bound decode stream. */
+int odic_beam_reset(const odic_beam_state* st, const odic_embed_args* emb, int32_t n_img, int32_t beams, int32_t T,
+                    int64_t sos_idx, void* stream);
 
 /* Final selection (captioning_model.py:225-241): score = cumul / n_elem, descending order per
  * image → order int32 [n_img, beams], score fp32 [n_img, beams]. */

@@ -41,6 +41,12 @@ class BeamState(C.Structure):
                  "pos", "done", "ctr")]
 
 
+class EmbedArgs(C.Structure):
+    """odic_embed_args: the next position's input embedding as the tail of the launch that chooses the words."""
+    _fields_ = [("embed", C.c_void_p), ("pos_table", C.c_void_p), ("y", C.c_void_p), ("ldy", C.c_int64),
+                ("d", C.c_int32), ("scale", C.c_float)]
+
+
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 _SIGNATURES = {
@@ -63,10 +69,12 @@ _SIGNATURES = {
     "odic_logsoftmax_sample": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, C.c_uint64, _P, _P]),
     "odic_ensemble_logprobs": (C.c_int, [C.POINTER(C.c_void_p), _I32, _I64, _P, _I64, _I32, _I32, _P]),
     "odic_topk_rows": (C.c_int, [_P, _I64, _P, _P, _I32, _I32, _I32, _P]),
-    "odic_beam_step": (C.c_int, [_P, _P, C.POINTER(BeamState), _I32, _I32, _I32, _I64, _P]),
+    "odic_beam_step": (C.c_int, [_P, _P, C.POINTER(BeamState), C.POINTER(EmbedArgs), _I32, _I32, _I32, _I64, _P]),
+    "odic_beam_search_step": (C.c_int, [_P, _I64, _I32, C.POINTER(BeamState), C.POINTER(EmbedArgs), _I32, _I32, _I32,
+                                        _I64, _P]),
     "odic_beam_finalize": (C.c_int, [C.POINTER(BeamState), _P, _P, _I32, _I32, _P]),
     "odic_beam_finalize_best": (C.c_int, [C.POINTER(BeamState), _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
-    "odic_beam_reset": (C.c_int, [C.POINTER(BeamState), _I32, _I32, _I32, _I64, _P]),
+    "odic_beam_reset": (C.c_int, [C.POINTER(BeamState), C.POINTER(EmbedArgs), _I32, _I32, _I32, _I64, _P]),
 }
 
 #: every symbol include/odic_hip.h declares

@@ -224,8 +224,8 @@ class CaptioningModel(nn.Module):
         T = steps + 1
         enc_len = self._enc_lens(B, S, enc_input_num_pads)
         st = eng.new_state(B, k, T, eng.project_kv(mem), enc_len)
-        st.tokens[:, :, 0] = sos_idx
-        st.next_tok.fill_(sos_idx)
+        # start state; for the deterministic search also the embedded start token as the input of position 0
+        ops.beam_reset(st.beam_state, B, k, T, sos_idx, emb=None if sample else st.emb)
         V = eng.g.vocab_size
         seed = self._next_sampling_seed() if sample else 0
         for t in range(steps):

@@ -376,89 +376,158 @@ __global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __res
 // Σ exp(x - max).  Then k rounds of block arg-max over the thread heads; the winner pops its
 // head.  Ties → lower index (within a thread indices ascend, across threads compared explicitly).
 // ---------------------------------------------------------------------------------------------
-template <int KM, bool NORM = true>
-__global__ __launch_bounds__(1024) void logsoftmax_topk_kernel(const float* __restrict__ logits, long ldl,
-                                                               float* __restrict__ logp_out, long ldp,
-                                                               float* __restrict__ top_val, int* __restrict__ top_idx,
-                                                               int V, int k) {
-  __shared__ float red[16];
-  __shared__ float bv[16];
-  __shared__ int bi[16];
-  __shared__ int winner;
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* x = logits + (long)n * ldl;
-  float tv[KM]; int ti[KM];
-#pragma unroll
-  for (int q = 0; q < KM; ++q) { tv[q] = -INFINITY; ti[q] = 0x7fffffff; }
-  // V <= 10240 (the 10000-word vocabulary): the row slice of a thread is 10 values — load them all at
-  // once and keep them in registers for both passes; longer rows stream twice.
-  constexpr int NPT = 10;
-  const bool small = V <= NPT * 1024;
-  float xv[NPT];
+// Up to NR rows AT ONCE (the fused search step: the k logits rows of one image; the stand-alone kernel: NR = 1): every
+// reduction carries NR values, so the barrier count is that of a single row, and a row's arithmetic and its order
+// do not depend on NR — both users produce identical candidates.  `top_val` / `top_idx` ([row][k]) may point to global
+// memory or LDS (the fused step keeps the candidates on chip); logp0 (optional): the full log-prob rows (ldp).
+template <int NR> struct TopkSharedN { float red[NR][16]; float bv[NR][16]; int bi[NR][16]; int winner[NR]; };
+
+template <int KM, int NR, int NTH, bool NORM>
+__device__ __forceinline__ void rows_logsoftmax_topk(const float* __restrict__ x0, long ldl, int nr,
+                                                     float* __restrict__ logp0, long ldp, float* top_val,
+                                                     int* top_idx, int V, int k, TopkSharedN<NR>& sh) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float tv[NR][KM]; int ti[NR][KM];
+  constexpr int NPT = 10240 / NTH, NWV = NTH / 64;
+  const bool small = V <= NPT * NTH;
+  float xv[NR][NPT];                       // V <= 10240: the thread's slice of every row stays in registers
   if (small) {
 #pragma unroll
-    for (int u = 0; u < NPT; ++u) { const int i = tid + u * 1024; xv[u] = i < V ? x[i] : -INFINITY; }
+    for (int r = 0; r < NR; ++r) {
+      const float* x = x0 + (long)min(r, nr - 1) * ldl;
 #pragma unroll
-    for (int u = 0; u < NPT; ++u) {
-      float v = xv[u]; int vi = tid + u * 1024;
-      if (v > tv[KM - 1]) {
-#pragma unroll
-        for (int q = 0; q < KM; ++q) {
-          if (v > tv[q]) { const float fv = tv[q]; const int fi = ti[q]; tv[q] = v; ti[q] = vi; v = fv; vi = fi; }
-        }
-      }
+      for (int u = 0; u < NPT; ++u) { const int i = tid + u * NTH; xv[r][u] = i < V ? x[i] : -INFINITY; }
     }
-  } else {
-    for (int i = tid; i < V; i += 1024) {
-      float v = x[i]; int vi = i;
-      if (v > tv[KM - 1]) {
+  }
 #pragma unroll
-        for (int q = 0; q < KM; ++q) {
-          if (v > tv[q]) { const float fv = tv[q]; const int fi = ti[q]; tv[q] = v; ti[q] = vi; v = fv; vi = fi; }
+  for (int r = 0; r < NR; ++r) {
+#pragma unroll
+    for (int q = 0; q < KM; ++q) { tv[r][q] = -INFINITY; ti[r][q] = 0x7fffffff; }
+    if (r < nr) {
+      const float* x = x0 + (long)r * ldl;
+      if (small) {
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+          float v = xv[r][u]; int vi = tid + u * NTH;
+          if (v > tv[r][KM - 1]) {
+#pragma unroll
+            for (int q = 0; q < KM; ++q) {
+              if (v > tv[r][q]) { const float fv = tv[r][q]; const int fi = ti[r][q]; tv[r][q] = v; ti[r][q] = vi; v = fv; vi = fi; }
+            }
+          }
+        }
+      } else {
+        for (int i = tid; i < V; i += NTH) {
+          float v = x[i]; int vi = i;
+          if (v > tv[r][KM - 1]) {
+#pragma unroll
+            for (int q = 0; q < KM; ++q) {
+              if (v > tv[r][q]) { const float fv = tv[r][q]; const int fi = ti[r][q]; tv[r][q] = v; ti[r][q] = vi; v = fv; vi = fi; }
+            }
+          }
         }
       }
     }
   }
-  float lse = 0.f;                                               // NORM = false: rows are log-probs already
+  float lse[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) lse[r] = 0.f;                     // NORM = false: rows are log-probs already
   if constexpr (NORM) {
-    const float m = block_max(tv[0], red);
-    float s = 0.f;
-    if (small) {
-#pragma unroll
-      for (int u = 0; u < NPT; ++u) s += expf(xv[u] - m);      // exp(-inf) = 0 for the padding slots
-    } else {
-      for (int i = tid; i < V; i += 1024) s += expf(x[i] - m);
-    }
-    s = block_sum(s, red);
-    lse = m + logf(s);
-  }
-  if (logp_out)
-    for (int i = tid; i < V; i += 1024) logp_out[(long)n * ldp + i] = x[i] - lse;
-  for (int r = 0; r < k; ++r) {
-    float best = tv[0]; int besti = ti[0];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(besti, o, 64);
-      if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-    }
-    if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
+    // row maxima
     __syncthreads();
-    if (tid == 0) {
-      float b = bv[0]; int ix = bi[0];
-      for (int w = 1; w < 16; ++w)
-        if (bv[w] > b || (bv[w] == b && bi[w] < ix)) { b = bv[w]; ix = bi[w]; }
-      winner = ix;
-      top_val[(long)n * k + r] = b - lse;
-      top_idx[(long)n * k + r] = ix;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const float m = wave_max(tv[r][0]);
+      if (lane == 0) sh.red[r][wave] = m;
     }
     __syncthreads();
-    if (ti[0] == winner) {                 // pop (static shifts keep the array in registers)
+    float mx[NR];
 #pragma unroll
-      for (int q = 0; q + 1 < KM; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
-      tv[KM - 1] = -INFINITY; ti[KM - 1] = 0x7fffffff;
+    for (int r = 0; r < NR; ++r) {
+      float t = sh.red[r][0];
+      for (int i = 1; i < NWV; ++i) t = fmaxf(t, sh.red[r][i]);
+      mx[r] = t;
+    }
+    // Σ exp(x - max)
+    float sm[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      float sacc = 0.f;
+      if (r < nr) {
+        const float* x = x0 + (long)r * ldl;
+        if (small) {
+#pragma unroll
+          for (int u = 0; u < NPT; ++u) sacc += expf(xv[r][u] - mx[r]);
+        } else {
+          for (int i = tid; i < V; i += NTH) sacc += expf(x[i] - mx[r]);
+        }
+      }
+      sm[r] = wave_sum(sacc);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+      if (lane == 0) sh.red[r][wave] = sm[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      float t = 0.f;
+      for (int i = 0; i < NWV; ++i) t += sh.red[r][i];
+      lse[r] = mx[r] + logf(t);
     }
   }
+  if (logp0) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+      if (r < nr)
+        for (int i = tid; i < V; i += NTH) logp0[(long)r * ldp + i] = x0[(long)r * ldl + i] - lse[r];
+  }
+  for (int rd = 0; rd < k; ++rd) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      float best = tv[r][0]; int besti = ti[r][0];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+      }
+      if (lane == 0) { sh.bv[r][wave] = best; sh.bi[r][wave] = besti; }
+    }
+    __syncthreads();
+    if (tid < nr) {
+      const int r = tid;
+      float bb = sh.bv[r][0]; int ix = sh.bi[r][0];
+      for (int w = 1; w < NWV; ++w)
+        if (sh.bv[r][w] > bb || (sh.bv[r][w] == bb && sh.bi[r][w] < ix)) { bb = sh.bv[r][w]; ix = sh.bi[r][w]; }
+      sh.winner[r] = ix;
+      float l = lse[0];
+#pragma unroll
+      for (int q = 1; q < NR; ++q) if (r == q) l = lse[q];
+      top_val[r * k + rd] = bb - l;
+      top_idx[r * k + rd] = ix;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      if (ti[r][0] == sh.winner[r] && r < nr) {
+#pragma unroll
+        for (int q = 0; q + 1 < KM; ++q) { tv[r][q] = tv[r][q + 1]; ti[r][q] = ti[r][q + 1]; }
+        tv[r][KM - 1] = -INFINITY; ti[r][KM - 1] = 0x7fffffff;
+      }
+    }
+  }
+}
+
+template <int KM, bool NORM = true>
+__global__ __launch_bounds__(512) void logsoftmax_topk_kernel(const float* __restrict__ logits, long ldl,
+                                                              float* __restrict__ logp_out, long ldp,
+                                                              float* __restrict__ top_val, int* __restrict__ top_idx,
+                                                              int V, int k) {
+  __shared__ TopkSharedN<1> sh;
+  const int n = blockIdx.x;
+  rows_logsoftmax_topk<KM, 1, 512, NORM>(logits + (long)n * ldl, ldl, 1, logp_out ? logp_out + (long)n * ldp : nullptr, ldp,
+                                         top_val + (long)n * k, top_idx + (long)n * k, V, k, sh);
 }
 
 
@@ -561,11 +630,14 @@ __global__ __launch_bounds__(1024) void logsoftmax_sample_kernel(const float* __
 }
 
 // ---------------------------------------------------------------------------------------------
-// Beam bookkeeping: one 64-lane block per image.  Lane 0 does the k·k selection, all lanes permute
-// the prefix / log-prob / ancestor rows IN PLACE (a lane owns whole columns j: it reads the k parent
-// values of its column first, then writes the k new rows).  The block that arrives last at `ctr`
-// (low 16 bits = arrivals, high bits = images with a still-growing beam) advances *pos, raises
-// *done when nothing grows any more, and re-arms the counter.
+// Beam bookkeeping: one block per image (captioning_model.py:172-223).  Wave 0 does the k·k selection — one lane per
+// candidate (four at k = 16), k rounds of a wave arg-max in which the lowest flat index wins a tie (the scan order
+// of the reference's topk over the flattened k x k scores) — then all threads permute the prefix / log-prob /
+// ancestor rows IN PLACE (a thread owns whole columns j: it reads the k parent values of its column first, then
+// writes the k new rows) and, when asked to, write the embedding of the chosen words for the next position
+// (EmbeddingLayer, layers.py:118-121: what odic_dec_embed would do in its own launch).  The block that arrives last
+// at `ctr` (low 16 bits = arrivals, high bits = images with a still-growing beam) advances *pos, raises *done when
+// nothing grows any more, and re-arms the counter.
 // ---------------------------------------------------------------------------------------------
 struct BeamParams {
   const float* cand_val; const int* cand_idx;
@@ -574,123 +646,183 @@ struct BeamParams {
   int* pos; int* done; int* ctr;
   int n_img, k, T; long long eos;
 };
+struct EmbedArgs { const float* embed; const float* pos_table; float* y; long ldy; int d; float scale; };
 
-__global__ __launch_bounds__(64) void beam_step_kernel(BeamParams p) {
-  __shared__ int s_parent[MAX_K];
-  __shared__ int s_word[MAX_K];
-  __shared__ float s_lp[MAX_K];
-  __shared__ float s_cumul[MAX_K];
-  const int lane = threadIdx.x, b = blockIdx.x;
-  const int k = p.k, T = p.T;
-  const int t = *p.pos;                 // position just processed; prefix length is t+1
-  if (t + 1 >= T) return;               // the prefix is full: a replay past the last step changes nothing
-  int alive_any = 0;
+struct BeamShared {
+  float cv[MAX_K * MAX_K]; int ci[MAX_K * MAX_K];      // candidates: log-prob, word  [beam][rank]
+  int eos[MAX_K]; int ne[MAX_K]; float cu[MAX_K];
+  float lpm[MAX_K][MAX_T];                             // per-token log-probs of the k prefixes
+  int parent[MAX_K]; int word[MAX_K]; float lp[MAX_K]; float cumul[MAX_K];
+};
 
-  // everything lane 0's serial selection touches is first brought into LDS by all 64 lanes
-  // (k² candidates, per-beam flags, the k x (t+1) per-token log-probs): one round of loads in flight
-  // instead of ~k·(t+k) dependent ones
-  __shared__ float s_cv[MAX_K * MAX_K];
-  __shared__ int s_ci[MAX_K * MAX_K];
-  __shared__ int s_eos[MAX_K];
-  __shared__ int s_ne[MAX_K];
-  __shared__ float s_cu[MAX_K];
-  __shared__ float s_lpm[MAX_K][MAX_T];
-  for (int i = lane; i < k * k; i += 64) {
-    s_cv[i] = p.cand_val[(long)b * k * k + i];
-    s_ci[i] = p.cand_idx[(long)b * k * k + i];
+// s.cv / s.ci hold the k x k candidates (written by this block; a barrier follows inside)
+template <int NT>
+__device__ __forceinline__ void beam_update(const BeamParams& p, const EmbedArgs& e, BeamShared& s, int b, int t) {
+  const int tid = threadIdx.x, k = p.k, T = p.T;
+  for (int r = tid; r < k; r += NT) {
+    s.eos[r] = p.has_eos[b * k + r]; s.ne[r] = p.n_elem[b * k + r]; s.cu[r] = p.cumul[b * k + r];
   }
-  for (int r = lane; r < k; r += 64) {
-    s_eos[r] = p.has_eos[b * k + r]; s_ne[r] = p.n_elem[b * k + r]; s_cu[r] = p.cumul[b * k + r];
-  }
-  for (int i = lane; i < k * (t + 1); i += 64) {
+  for (int i = tid; i < k * (t + 1); i += NT) {
     const int r = i / (t + 1), j = i - r * (t + 1);
-    s_lpm[r][j] = p.lp[((long)b * k + r) * T + j];
+    s.lpm[r][j] = p.lp[((long)b * k + r) * T + j];
   }
   __syncthreads();
 
-  if (lane == 0) {
+  if (tid < 64) {
+    const int lane = tid;
     if (t == 0) {                       // seeding: the k best words of beam 0
-      for (int r = 0; r < k; ++r) {
-        s_parent[r] = 0;
-        s_word[r] = s_ci[r];
-        s_lp[r] = s_cv[r];
-      }
+      if (lane < k) { s.parent[lane] = 0; s.word[lane] = s.ci[lane]; s.lp[lane] = s.cv[lane]; }
     } else {
-      float tot[MAX_K * MAX_K];
-      for (int j = 0; j < k; ++j) {
-        const int dn = s_eos[j];
-        const float cu = s_cu[j];
-        for (int c = 0; c < k; ++c) {
-          const float v = dn ? (c == 0 ? 0.0f : -999.0f) : s_cv[j * k + c];
-          tot[j * k + c] = cu + v;
+      constexpr int CPL = MAX_K * MAX_K / 64;        // candidates per lane
+      float tot[CPL], val[CPL];
+#pragma unroll
+      for (int u = 0; u < CPL; ++u) {
+        const int i = lane + 64 * u;
+        tot[u] = -INFINITY; val[u] = 0.f;
+        if (i < k * k) {
+          const int j = i / k, c = i - j * k;
+          val[u] = s.eos[j] ? (c == 0 ? 0.0f : -999.0f) : s.cv[i];
+          tot[u] = s.cu[j] + val[u];
         }
       }
       for (int r = 0; r < k; ++r) {
-        int bi = 0; float bvv = -INFINITY;
-        for (int i = 0; i < k * k; ++i)
-          if (tot[i] > bvv) { bvv = tot[i]; bi = i; }
-        tot[bi] = -INFINITY;
-        const int j = bi / k, c = bi - j * k;
-        const int dn = s_eos[j];
-        s_parent[r] = j;
-        s_word[r] = s_ci[j * k + c];
-        s_lp[r] = dn ? (c == 0 ? 0.0f : -999.0f) : s_cv[j * k + c];
+        float best = tot[0], bval = val[0]; int bi = lane;
+#pragma unroll
+        for (int u = 1; u < CPL; ++u)
+          if (tot[u] > best) { best = tot[u]; bval = val[u]; bi = lane + 64 * u; }
+        if (!(best > -INFINITY)) bi = 0x7fffffff;               // nothing left in this lane
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(best, o, 64), ol = __shfl_xor(bval, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ov > best || (ov == best && oi < bi)) { best = ov; bval = ol; bi = oi; }
+        }
+#pragma unroll
+        for (int u = 0; u < CPL; ++u)
+          if (bi == lane + 64 * u) tot[u] = -INFINITY;
+        if (lane == 0) { s.parent[r] = bi / k; s.word[r] = s.ci[bi]; s.lp[r] = bval; }
       }
-    }
-    // cumulative score = re-summed per-token log-probs of the parent prefix + the new one (:213)
-    for (int r = 0; r < k; ++r) {
-      const float* src = s_lpm[s_parent[r]];
-      float cs = 0.f;
-      for (int j = 0; j <= t; ++j) cs += src[j];
-      s_cumul[r] = cs + s_lp[r];
     }
   }
   __syncthreads();
+  // cumulative score = re-summed per-token log-probs of the parent prefix + the new one (:213), in position order
+  if (tid < k) {
+    const float* src = s.lpm[s.parent[tid]];
+    float cs = 0.f;
+    for (int j = 0; j <= t; ++j) cs += src[j];
+    s.cumul[tid] = cs + s.lp[tid];
+  }
   const long base = (long)b * k * T;
-  for (int j = lane; j <= t; j += 64) {
-    long long tv[MAX_K]; float lv[MAX_K]; int av[MAX_K];
+  if constexpr (NT >= 256) {
+    // one (row, column) element per thread and pass: all reads of the old rows, a barrier, then the writes
+    constexpr int EPT = (MAX_K * MAX_T + NT - 1) / NT;
+    long long tv[EPT]; float lv[EPT]; int av[EPT];
+    const int cols = t + 1;
 #pragma unroll
-    for (int r = 0; r < MAX_K; ++r) {
-      if (r < k) {
-        const long src = base + (long)s_parent[r] * T + j;
-        tv[r] = p.tok[src]; lv[r] = p.lp[src];
-        av[r] = j < t ? p.anc[src] : b * k + s_parent[r];
+    for (int u = 0; u < EPT; ++u) {
+      const int i = tid + u * NT;
+      if (i < k * cols) {
+        const int r = i / cols, j = i - r * cols;
+        const long src = base + (long)s.parent[r] * T + j;
+        tv[u] = p.tok[src]; lv[u] = p.lp[src];
+        av[u] = j < t ? p.anc[src] : b * k + s.parent[r];
       }
     }
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < MAX_K; ++r) {
-      if (r < k) {
+    for (int u = 0; u < EPT; ++u) {
+      const int i = tid + u * NT;
+      if (i < k * cols) {
+        const int r = i / cols, j = i - r * cols;
         const long dst = base + (long)r * T + j;
-        p.tok[dst] = tv[r]; p.lp[dst] = lv[r]; p.anc[dst] = av[r];
+        p.tok[dst] = tv[u]; p.lp[dst] = lv[u]; p.anc[dst] = av[u];
+      }
+    }
+  } else {
+    for (int j = tid; j <= t; j += NT) {                // a thread owns whole columns
+      long long tv[MAX_K]; float lv[MAX_K]; int av[MAX_K];
+#pragma unroll
+      for (int r = 0; r < MAX_K; ++r) {
+        if (r < k) {
+          const long src = base + (long)s.parent[r] * T + j;
+          tv[r] = p.tok[src]; lv[r] = p.lp[src];
+          av[r] = j < t ? p.anc[src] : b * k + s.parent[r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < MAX_K; ++r) {
+        if (r < k) {
+          const long dst = base + (long)r * T + j;
+          p.tok[dst] = tv[r]; p.lp[dst] = lv[r]; p.anc[dst] = av[r];
+        }
       }
     }
   }
-  if (lane == 0) {
-    int pe[MAX_K], ne[MAX_K];
-    for (int r = 0; r < k; ++r) {
-      const int par = s_parent[r];
-      pe[r] = t == 0 ? 0 : s_eos[par];
-      ne[r] = t == 0 ? 1 : s_ne[par];
-    }
-    for (int r = 0; r < k; ++r) {
-      const long dst = base + (long)r * T;
-      p.tok[dst + t + 1] = (long long)s_word[r];
-      p.lp[dst + t + 1] = s_lp[r];
-      p.cumul[b * k + r] = s_cumul[r];
-      p.n_elem[b * k + r] = ne[r] + (pe[r] ? 0 : 1);
-      p.has_eos[b * k + r] = (pe[r] || ((long long)s_word[r] == p.eos)) ? 1 : 0;
-      p.row_valid[b * k + r] = pe[r] ? 0 : 1;
-      p.next_tok[b * k + r] = (long long)s_word[r];
-      if (!pe[r]) alive_any = 1;
-    }
-    const int prev = atomicAdd(p.ctr, 1 + (alive_any << 16));
-    if ((prev & 0xffff) == p.n_img - 1) {            // every block has read *pos before arriving here
-      const int alive = (prev >> 16) + alive_any;
-      if (!alive) *p.done = 1;
-      *p.pos = t + 1;
-      *p.ctr = 0;
+  if (e.embed && t + 2 < T) {                           // input of the next position for the k chosen words (the
+                                                        // last prefix position T-1 is never fed back)
+    const float* prow = e.pos_table + (long)(t + 1) * e.d;
+    for (int i = tid; i < k * e.d; i += NT) {
+      const int r = i / e.d, c = i - r * e.d;
+      e.y[(long)(b * k + r) * e.ldy + c] = e.embed[(long)s.word[r] * e.d + c] * e.scale + prow[c];
     }
   }
+  __syncthreads();                                      // s.cumul; every thread's reads of the old rows are done
+  int alive = 0;
+  if (tid < k) {
+    const int r = tid, par = s.parent[r];
+    const int pe = t == 0 ? 0 : s.eos[par];
+    const int ne = t == 0 ? 1 : s.ne[par];
+    const long dst = base + (long)r * T;
+    p.tok[dst + t + 1] = (long long)s.word[r];
+    p.lp[dst + t + 1] = s.lp[r];
+    p.cumul[b * k + r] = s.cumul[r];
+    p.n_elem[b * k + r] = ne + (pe ? 0 : 1);
+    p.has_eos[b * k + r] = (pe || ((long long)s.word[r] == p.eos)) ? 1 : 0;
+    p.row_valid[b * k + r] = pe ? 0 : 1;
+    p.next_tok[b * k + r] = (long long)s.word[r];
+    alive = pe ? 0 : 1;
+  }
+  if (tid < 64) {
+    const int alive_any = __any(alive) ? 1 : 0;         // (k <= 16 lanes of wave 0 carry the flags)
+    if (tid == 0) {
+      const int prev = atomicAdd(p.ctr, 1 + (alive_any << 16));
+      if ((prev & 0xffff) == p.n_img - 1) {             // every block has read *pos before arriving here
+        const int al = (prev >> 16) + alive_any;
+        if (!al) *p.done = 1;
+        *p.pos = t + 1;
+        *p.ctr = 0;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void beam_step_kernel(BeamParams p, EmbedArgs e) {
+  __shared__ BeamShared s;
+  const int b = blockIdx.x, k = p.k;
+  const int t = *p.pos;                 // position just processed; prefix length is t+1
+  if (t + 1 >= p.T) return;             // the prefix is full: a replay past the last step changes nothing
+  for (int i = threadIdx.x; i < k * k; i += 64) {
+    s.cv[i] = p.cand_val[(long)b * k * k + i];
+    s.ci[i] = p.cand_idx[(long)b * k * k + i];
+  }
+  beam_update<64>(p, e, s, b, t);
+}
+
+// The whole tail of a search step in one launch: log-softmax + top-k of the image's k logits rows, NR rows per pass
+// (the candidates stay in LDS), the beam update above and the next position's input embedding.
+template <int KM, int NR>
+__global__ __launch_bounds__(512) void beam_search_step_kernel(const float* __restrict__ logits, long ldl, int V,
+                                                                BeamParams p, EmbedArgs e) {
+  __shared__ BeamShared s;
+  __shared__ TopkSharedN<NR> sh;
+  const int b = blockIdx.x, k = p.k;
+  const int t = *p.pos;
+  if (t + 1 >= p.T) return;
+  const int nrows = t == 0 ? 1 : k;     // at the first position only beam 0 seeds the search
+  for (int r0 = 0; r0 < nrows; r0 += NR)
+    rows_logsoftmax_topk<KM, NR, 512, true>(logits + (long)(b * k + r0) * ldl, ldl, min(NR, nrows - r0), nullptr, 0, s.cv + r0 * k,
+                                 s.ci + r0 * k, V, k, sh);
+  beam_update<512>(p, e, s, b, t);
 }
 
 __global__ void beam_finalize_kernel(const float* cumul, const int* n_elem, int* order, float* score, int n_img,
@@ -733,10 +865,15 @@ __global__ __launch_bounds__(64) void beam_finalize_best_kernel(const float* cum
 }
 
 __global__ void beam_reset_kernel(long long* tok, float* lp, int* row_valid, long long* next_tok, int* pos,
-                                  int* done, int* ctr, int N, int T, long long sos) {
+                                  int* done, int* ctr, int N, int T, long long sos, EmbedArgs e) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) { tok[(long)i * T] = sos; lp[(long)i * T] = 0.f; row_valid[i] = 1; next_tok[i] = sos; }
   if (i == 0) { *pos = 0; *done = 0; *ctr = 0; }
+  if (e.embed)                                          // input of position 0: the start token
+    for (long q = i; q < (long)N * e.d; q += (long)gridDim.x * blockDim.x) {
+      const long r = q / e.d; const int c = (int)(q - r * e.d);
+      e.y[r * e.ldy + c] = e.embed[sos * e.d + c] * e.scale + e.pos_table[c];
+    }
 }
 
 }  // namespace
@@ -845,9 +982,9 @@ extern "C" int odic_topk_rows(const float* logp, int64_t ldl, float* top_val, in
   if (!logp || !top_val || !top_idx) return ODIC_ENULL;
   if (N <= 0 || V <= 0 || k <= 0 || k > MAX_K || k > V) return ODIC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (k <= 4) hipLaunchKernelGGL((logsoftmax_topk_kernel<4, false>), dim3(N), dim3(1024), 0, s, logp, (long)ldl, (float*)nullptr, 0L, top_val, top_idx, V, k);
-  else if (k <= 8) hipLaunchKernelGGL((logsoftmax_topk_kernel<8, false>), dim3(N), dim3(1024), 0, s, logp, (long)ldl, (float*)nullptr, 0L, top_val, top_idx, V, k);
-  else hipLaunchKernelGGL((logsoftmax_topk_kernel<16, false>), dim3(N), dim3(1024), 0, s, logp, (long)ldl, (float*)nullptr, 0L, top_val, top_idx, V, k);
+  if (k <= 4) hipLaunchKernelGGL((logsoftmax_topk_kernel<4, false>), dim3(N), dim3(512), 0, s, logp, (long)ldl, (float*)nullptr, 0L, top_val, top_idx, V, k);
+  else if (k <= 8) hipLaunchKernelGGL((logsoftmax_topk_kernel<8, false>), dim3(N), dim3(512), 0, s, logp, (long)ldl, (float*)nullptr, 0L, top_val, top_idx, V, k);
+  else hipLaunchKernelGGL((logsoftmax_topk_kernel<16, false>), dim3(N), dim3(512), 0, s, logp, (long)ldl, (float*)nullptr, 0L, top_val, top_idx, V, k);
   return odic_launch_status();
 }
 
@@ -856,27 +993,61 @@ extern "C" int odic_logsoftmax_topk(const float* logits, int64_t ldl, float* log
   if (!logits || !top_val || !top_idx) return ODIC_ENULL;
   if (N <= 0 || V <= 0 || k <= 0 || k > MAX_K || k > V) return ODIC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (k <= 4) hipLaunchKernelGGL(logsoftmax_topk_kernel<4>, dim3(N), dim3(1024), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
-  else if (k <= 8) hipLaunchKernelGGL(logsoftmax_topk_kernel<8>, dim3(N), dim3(1024), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
-  else hipLaunchKernelGGL(logsoftmax_topk_kernel<16>, dim3(N), dim3(1024), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
+  if (k <= 4) hipLaunchKernelGGL(logsoftmax_topk_kernel<4>, dim3(N), dim3(512), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
+  else if (k <= 8) hipLaunchKernelGGL(logsoftmax_topk_kernel<8>, dim3(N), dim3(512), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
+  else hipLaunchKernelGGL(logsoftmax_topk_kernel<16>, dim3(N), dim3(512), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
   return odic_launch_status();
 }
 
-extern "C" int odic_beam_step(const float* cand_val, const int32_t* cand_idx, const odic_beam_state* st,
-                              int32_t n_img, int32_t beams, int32_t T, int64_t eos_idx, void* stream) {
-  if (!cand_val || !cand_idx || !st) return ODIC_ENULL;
-  // T: k x (t+1) per-token log-probs are staged in s_lpm[MAX_K][MAX_T]; n_img: `alive << 16` in the counter
+static int beam_params(BeamParams& p, EmbedArgs& e, const odic_beam_state* st, const odic_embed_args* emb,
+                       int32_t n_img, int32_t beams, int32_t T, int64_t eos_idx) {
+  if (!st) return ODIC_ENULL;
+  // T: k x (t+1) per-token log-probs are staged in LDS [MAX_K][MAX_T]; n_img: `alive << 16` in the counter
   if (n_img <= 0 || beams <= 0 || beams > MAX_K || T <= 1 || T > MAX_T || n_img > 32767) return ODIC_EINVAL;
   if (!st->tokens || !st->logprobs || !st->anc || !st->cumul || !st->n_elem || !st->has_eos || !st->row_valid ||
       !st->next_tok || !st->pos || !st->done || !st->ctr)
     return ODIC_ENULL;
-  BeamParams p;
-  p.cand_val = cand_val; p.cand_idx = cand_idx;
+  p.cand_val = nullptr; p.cand_idx = nullptr;
   p.tok = (long long*)st->tokens; p.lp = st->logprobs; p.anc = st->anc;
   p.cumul = st->cumul; p.n_elem = st->n_elem; p.has_eos = st->has_eos; p.row_valid = st->row_valid;
   p.next_tok = (long long*)st->next_tok; p.pos = st->pos; p.done = st->done; p.ctr = st->ctr;
   p.n_img = n_img; p.k = beams; p.T = T; p.eos = eos_idx;
-  hipLaunchKernelGGL(beam_step_kernel, dim3(n_img), dim3(64), 0, (hipStream_t)stream, p);
+  e.embed = nullptr; e.pos_table = nullptr; e.y = nullptr; e.ldy = 0; e.d = 0; e.scale = 0.f;
+  if (emb) {
+    if (!emb->embed || !emb->pos_table || !emb->y) return ODIC_ENULL;
+    if (emb->d <= 0) return ODIC_EINVAL;
+    e.embed = emb->embed; e.pos_table = emb->pos_table; e.y = emb->y; e.ldy = emb->ldy; e.d = emb->d; e.scale = emb->scale;
+  }
+  return 0;
+}
+
+extern "C" int odic_beam_step(const float* cand_val, const int32_t* cand_idx, const odic_beam_state* st,
+                              const odic_embed_args* emb, int32_t n_img, int32_t beams, int32_t T, int64_t eos_idx,
+                              void* stream) {
+  if (!cand_val || !cand_idx) return ODIC_ENULL;
+  BeamParams p; EmbedArgs e;
+  const int rc = beam_params(p, e, st, emb, n_img, beams, T, eos_idx);
+  if (rc != 0) return rc;
+  p.cand_val = cand_val; p.cand_idx = cand_idx;
+  hipLaunchKernelGGL(beam_step_kernel, dim3(n_img), dim3(64), 0, (hipStream_t)stream, p, e);
+  return odic_launch_status();
+}
+
+extern "C" int odic_beam_search_step(const float* logits, int64_t ldl, int32_t V, const odic_beam_state* st,
+                                     const odic_embed_args* emb, int32_t n_img, int32_t beams, int32_t T,
+                                     int64_t eos_idx, void* stream) {
+  if (!logits) return ODIC_ENULL;
+  BeamParams p; EmbedArgs e;
+  const int rc = beam_params(p, e, st, emb, n_img, beams, T, eos_idx);
+  if (rc != 0) return rc;
+  if (V <= 0 || beams > V) return ODIC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  // (per-thread top-list length >= beams, rows per pass): 512-thread blocks, so that a thread's 20-value slice of
+  // every row of the pass and its top lists fit the 256 registers without spilling
+  if (beams <= 4) hipLaunchKernelGGL((beam_search_step_kernel<4, 4>), dim3(n_img), dim3(512), 0, s, logits, (long)ldl, V, p, e);
+  else if (beams == 5) hipLaunchKernelGGL((beam_search_step_kernel<5, 5>), dim3(n_img), dim3(512), 0, s, logits, (long)ldl, V, p, e);
+  else if (beams <= 8) hipLaunchKernelGGL((beam_search_step_kernel<8, 4>), dim3(n_img), dim3(512), 0, s, logits, (long)ldl, V, p, e);
+  else hipLaunchKernelGGL((beam_search_step_kernel<16, 2>), dim3(n_img), dim3(512), 0, s, logits, (long)ldl, V, p, e);
   return odic_launch_status();
 }
 
@@ -900,16 +1071,23 @@ extern "C" int odic_beam_finalize_best(const odic_beam_state* st, int32_t* order
   return odic_launch_status();
 }
 
-extern "C" int odic_beam_reset(const odic_beam_state* st, int32_t n_img, int32_t beams, int32_t T, int64_t sos_idx,
-                               void* stream) {
+extern "C" int odic_beam_reset(const odic_beam_state* st, const odic_embed_args* emb, int32_t n_img, int32_t beams,
+                               int32_t T, int64_t sos_idx, void* stream) {
   if (!st) return ODIC_ENULL;
+  EmbedArgs e; e.embed = nullptr; e.pos_table = nullptr; e.y = nullptr; e.ldy = 0; e.d = 0; e.scale = 0.f;
+  if (emb) {
+    if (!emb->embed || !emb->pos_table || !emb->y) return ODIC_ENULL;
+    if (emb->d <= 0) return ODIC_EINVAL;
+    e.embed = emb->embed; e.pos_table = emb->pos_table; e.y = emb->y; e.ldy = emb->ldy; e.d = emb->d; e.scale = emb->scale;
+  }
   if (!st->tokens || !st->logprobs || !st->row_valid || !st->next_tok || !st->pos || !st->done || !st->ctr)
     return ODIC_ENULL;
   if (n_img <= 0 || beams <= 0 || beams > MAX_K || T <= 0) return ODIC_EINVAL;
   const int N = n_img * beams;
-  hipLaunchKernelGGL(beam_reset_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     (long long*)st->tokens, st->logprobs, st->row_valid, (long long*)st->next_tok, st->pos, st->done,
-                     st->ctr, N, T, (long long)sos_idx);
+  const int nblk = emb ? (int)(((long)N * e.d + 255) / 256 < 1024 ? ((long)N * e.d + 255) / 256 : 1024) : (N + 255) / 256;
+  hipLaunchKernelGGL(beam_reset_kernel, dim3(nblk < (N + 255) / 256 ? (N + 255) / 256 : nblk), dim3(256), 0,
+                     (hipStream_t)stream, (long long*)st->tokens, st->logprobs, st->row_valid,
+                     (long long*)st->next_tok, st->pos, st->done, st->ctr, N, T, (long long)sos_idx, e);
   return odic_launch_status();
 }
 

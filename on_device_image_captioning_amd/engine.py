@@ -234,6 +234,8 @@ class DecodeState:
         self.beam_state = _hip.BeamState(*(t.data_ptr() for t in (
             self.tokens, self.logprobs, self.anc, self.cumul, self.n_elem, self.has_eos, self.row_valid,
             self.next_tok, self.pos, self.done, self.ctr)))
+        # the next position's input embedding, written by the launch that chooses the words (odic_embed_args)
+        self.emb = ops.embed_args(eng.embed, eng.pos_table, self.ycat, L * d, d, math.sqrt(d))
 
 
 class CaptionerEngine:
@@ -393,12 +395,15 @@ class CaptionerEngine:
             raise RuntimeError(f"{T - 1} decode positions exceed the pos_encoder table ({self.pos_table.shape[0]})")
         return DecodeState(self, n_img, beams, T, kv, enc_len, kv.shape[1])
 
-    def step_logits(self, st: DecodeState) -> None:
-        """Process position *st.pos for every sequence: next_tok → st.logits [N,V]."""
+    def step_logits(self, st: DecodeState, embed: bool = True) -> None:
+        """Process position *st.pos for every sequence: next_tok → st.logits [N,V].  embed=False: the input row of
+        this position is already in st.ycat (written by the launch that chose the word: beam_reset / beam_search_step
+        with st.emb)."""
         g = self.g
         d, L, N = g.d_model, g.N_dec, st.N
         ld = L * d
-        ops.dec_embed(st.next_tok, self.embed, self.pos_table, st.pos, st.ycat, ld, N, d, math.sqrt(d))
+        if embed:
+            ops.dec_embed(st.next_tok, self.embed, self.pos_table, st.pos, st.ycat, ld, N, d, math.sqrt(d))
         # the folded-LayerNorm form lives in the skinny-M kernel (M <= 192 rows, gemm_f32.hip); wider
         # searches (batch 64 x beam 5, decode groups) take the LayerNorm + GEMM pair
         fuse = self.fuse_ln and N <= 192
@@ -437,8 +442,8 @@ class CaptionerEngine:
             ops.gemm(ops.layernorm(pre, self.drn_w, self.drn_b), self.voc_w, self.voc_b, out=st.logits)
 
     def beam_step(self, st: DecodeState, eos_idx: int) -> None:
-        """One full search step: decoder → log-softmax/top-k → on-device beam bookkeeping."""
-        self.step_logits(st)
+        """One full search step: decoder → log-softmax / top-k / beam bookkeeping / next input, the tail as ONE
+        launch.  The state must have been armed with ops.beam_reset(st.beam_state, ..., emb=st.emb)."""
+        self.step_logits(st, embed=False)
         V = self.g.vocab_size
-        ops.logsoftmax_topk(st.logits, V, None, 0, st.cand_val, st.cand_idx, st.N, V, st.beams)
-        ops.beam_step(st.cand_val, st.cand_idx, st.beam_state, st.n_img, st.beams, st.T, eos_idx)
+        ops.beam_search_step(st.logits, V, V, st.beam_state, st.n_img, st.beams, st.T, eos_idx, emb=st.emb)

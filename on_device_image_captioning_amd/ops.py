@@ -471,12 +471,35 @@ def topk_rows(logp: torch.Tensor, top_val: torch.Tensor, top_idx: torch.Tensor, 
                    "odic_topk_rows")
 
 
-def beam_step(cand_val, cand_idx, state: "_hip.BeamState", n_img, beams, T, eos_idx) -> None:
-    # k² candidates in, the k prefixes (token int64, log-prob, ancestor) of t+1 positions read and re-written
+def embed_args(embed, pos_table, y, ldy, d, scale) -> "_hip.EmbedArgs":
+    """odic_embed_args for beam_step / beam_search_step / beam_reset (the caller keeps the tensors alive)."""
+    _need_cuda(embed, pos_table, y)
+    return _hip.EmbedArgs(_p(embed), _p(pos_table), _p(y), ldy, d, scale)
+
+
+def _emb_ref(emb):
+    return C.byref(emb) if emb is not None else None
+
+
+def _beam_bytes(n_img, beams, T, emb):
+    # the k prefixes (token int64, log-prob, ancestor) of t+1 positions read and re-written, per-beam flags, and
+    # with the embedding tail one table row in and one input row out per beam
     t = _STEP_T if _STEP_T is not None else (T - 1) / 2.0
-    with _timed("beam_step", 0.0, n_img * (beams * beams * 8.0 + 2.0 * beams * (t + 1) * 16.0 + beams * 32.0)):
-        _hip.check(_hip.load().odic_beam_step(_p(cand_val), _p(cand_idx), C.byref(state), n_img, beams, T, eos_idx,
-                                              _stream()), "odic_beam_step")
+    return n_img * (2.0 * beams * (t + 1) * 16.0 + beams * 32.0 + (beams * emb.d * 8.0 if emb is not None else 0.0))
+
+
+def beam_step(cand_val, cand_idx, state: "_hip.BeamState", n_img, beams, T, eos_idx, emb=None) -> None:
+    with _timed("beam_step", 0.0, n_img * beams * beams * 8.0 + _beam_bytes(n_img, beams, T, emb)):
+        _hip.check(_hip.load().odic_beam_step(_p(cand_val), _p(cand_idx), C.byref(state), _emb_ref(emb), n_img, beams,
+                                              T, eos_idx, _stream()), "odic_beam_step")
+
+
+def beam_search_step(logits, ldl, V, state: "_hip.BeamState", n_img, beams, T, eos_idx, emb=None) -> None:
+    """log-softmax + top-k of the step's logits rows, the beam update and (emb) the next input, in one launch."""
+    _need_cuda(logits)
+    with _timed("beam_search_step", 4.0 * n_img * beams * V, n_img * beams * V * 4.0 + _beam_bytes(n_img, beams, T, emb)):
+        _hip.check(_hip.load().odic_beam_search_step(_p(logits), ldl, V, C.byref(state), _emb_ref(emb), n_img, beams, T,
+                                                     eos_idx, _stream()), "odic_beam_search_step")
 
 
 def beam_finalize(state: "_hip.BeamState", order, score, n_img, beams) -> None:
@@ -493,9 +516,10 @@ def beam_finalize_best(state: "_hip.BeamState", order, score, out_tok, out_len, 
                                                        n_img, beams, T, pad_idx, _stream()), "odic_beam_finalize_best")
 
 
-def beam_reset(state: "_hip.BeamState", n_img, beams, T, sos_idx) -> None:
-    with _timed("beam_reset", 0.0, n_img * beams * 28.0):
-        _hip.check(_hip.load().odic_beam_reset(C.byref(state), n_img, beams, T, sos_idx, _stream()), "odic_beam_reset")
+def beam_reset(state: "_hip.BeamState", n_img, beams, T, sos_idx, emb=None) -> None:
+    with _timed("beam_reset", 0.0, n_img * beams * (28.0 + (emb.d * 4.0 if emb is not None else 0.0))):
+        _hip.check(_hip.load().odic_beam_reset(C.byref(state), _emb_ref(emb), n_img, beams, T, sos_idx, _stream()),
+                   "odic_beam_reset")
 
 
 def quantize_fp8_per_channel(w: torch.Tensor):

@@ -187,7 +187,9 @@ class CaptionPipeline:
 
     def _reset(self, lane: int) -> None:
         st = self.states[lane]
-        ops.beam_reset(st.beam_state, st.n_img, st.beams, st.T, self.sos)
+        # single model: the start token's embedding is part of the reset, every later input row part of the step's
+        # last launch (CaptionerEngine.beam_step); ensemble members embed for themselves in step_logits
+        ops.beam_reset(st.beam_state, st.n_img, st.beams, st.T, self.sos, emb=st.emb if self.M == 1 else None)
 
     def _capture(self) -> None:
         torch.cuda.synchronize()

@@ -56,10 +56,14 @@ def test_argument_validation_needs_no_gpu(lib):
     # odic_beam_step: per-token log-probs are staged in LDS for at most 128 positions, and the arrival counter
     # packs {arrivals, growing images} into one int32: both limits are rejected, not overrun
     st = _hip.BeamState(*([16] * 11))
-    assert lib.odic_beam_step(16, 16, ctypes.byref(st), 4, 3, 129, 77, None) == -1
-    assert lib.odic_beam_step(16, 16, ctypes.byref(st), 32768, 3, 20, 77, None) == -1
-    assert lib.odic_beam_step(16, 16, ctypes.byref(st), 4, 17, 20, 77, None) == -1
-    assert lib.odic_beam_reset(None, 4, 3, 20, 79, None) == -2
+    assert lib.odic_beam_step(16, 16, ctypes.byref(st), None, 4, 3, 129, 77, None) == -1
+    assert lib.odic_beam_step(16, 16, ctypes.byref(st), None, 32768, 3, 20, 77, None) == -1
+    assert lib.odic_beam_step(16, 16, ctypes.byref(st), None, 4, 17, 20, 77, None) == -1
+    assert lib.odic_beam_search_step(16, 100, 100, ctypes.byref(st), None, 4, 3, 129, 77, None) == -1
+    assert lib.odic_beam_search_step(None, 100, 100, ctypes.byref(st), None, 4, 3, 20, 77, None) == -2
+    emb = _hip.EmbedArgs(16, 16, None, 512, 512, 1.0)              # embedding tail asked for without an output
+    assert lib.odic_beam_step(16, 16, ctypes.byref(st), ctypes.byref(emb), 4, 3, 20, 77, None) == -2
+    assert lib.odic_beam_reset(None, None, 4, 3, 20, 79, None) == -2
     assert lib.odic_beam_finalize_best(ctypes.byref(st), 16, 16, None, 16, 4, 3, 20, 77, None) == -2
     assert lib.odic_logsoftmax_sample(16, 8, None, 0, 16, 16, 4, 8, 9, 0, None, None) == -1           # k > V
     # persistent bf16 tile configurations need the caller's workspace

@@ -426,6 +426,42 @@ def _beam_state(ops, n_img, k, T):
     return t, st
 
 
+@pytest.mark.parametrize("k,V", [(3, 1000), (5, 10000), (2, 12000), (9, 3000)])
+def test_beam_search_step_fused_equals_the_three_launches(ops, k, V):
+    """odic_beam_search_step (log-softmax + top-k + beam update + next input embedding in one launch) against
+    odic_logsoftmax_topk → odic_beam_step → odic_dec_embed on the same logits, bit for bit, over a whole search with
+    beams finishing on the way; a second search re-uses both states (counter re-armed, idempotent past the end)."""
+    n_img, T, sos, eos, d = 5, 11, 3, 4, 64
+    N = n_img * k
+    g = torch.Generator().manual_seed(11)
+    embed = dev(torch.randn(V, d, generator=g))
+    pos_table = dev(torch.randn(T, d, generator=g))
+    ta, sa = _beam_state(ops, n_img, k, T)
+    tb, sb = _beam_state(ops, n_img, k, T)
+    ya, yb = torch.zeros(N, 2 * d, device="cuda"), torch.zeros(N, 2 * d, device="cuda")
+    emb = ops.embed_args(embed, pos_table, yb, 2 * d, d, 8.0)
+    cv, ci = torch.zeros(N, k, device="cuda"), torch.zeros(N, k, dtype=torch.int32, device="cuda")
+    for search in range(2):
+        ops.beam_reset(sa, n_img, k, T, sos)
+        ops.dec_embed(ta["next_tok"], embed, pos_table, ta["pos"], ya, 2 * d, N, d, 8.0)
+        ops.beam_reset(sb, n_img, k, T, sos, emb=emb)
+        assert torch.equal(ya, yb)
+        for step in range(T + 1):                      # two launches past the last position: nothing may change
+            logits = torch.randn(N, V, generator=g) * 3.0
+            if step >= 2:
+                logits[torch.rand(N, generator=g) < 0.4, eos] = 12.0
+            lg = dev(logits)
+            ops.logsoftmax_topk(lg, V, None, 0, cv, ci, N, V, k)
+            ops.beam_step(cv, ci, sa, n_img, k, T, eos)
+            if step < T - 2:                           # (position T-1 is never an input)
+                ops.dec_embed(ta["next_tok"], embed, pos_table, ta["pos"], ya, 2 * d, N, d, 8.0)
+            ops.beam_search_step(lg, V, V, sb, n_img, k, T, eos, emb=emb)
+            for name in ta:
+                assert torch.equal(ta[name], tb[name]), f"search {search} step {step}: {name}"
+            assert torch.equal(ya, yb), f"search {search} step {step}: next input rows"
+        assert int(ta["pos"].item()) == T - 1 and int(ta["has_eos"].sum().item()) > 0
+
+
 def test_beam_step_direct_against_the_search_loop(ops):
     """odic_beam_reset / odic_beam_step / odic_beam_finalize(_best) on synthetic candidate tables, step by step
     against a plain restatement of captioning_model.py:117-241: EXACT ties in the k·k selection (lowest flat

@@ -24,9 +24,14 @@ def run():
 
     torch.set_grad_enabled(False)
     dev = torch.device("cuda", 0)
-    model, sd, g = bench.build_model(dev, "bf16", "e2e16")
-    pipe = CaptionPipeline(model, 16, 3, 20, 79, 77)
-    img = W.synth_images(16, g).to(dev)
+    wl = os.environ.get("ODIC_WL", "e2e16")
+    w = bench.WORKLOADS[wl]
+    model, sd, g = bench.build_model(dev, w["precision"], wl)
+    pipe = CaptionPipeline(model, w["batch"], w["beam"], w["max_len"], 79, 77)
+    if wl == "features48":
+        img = torch.randn(w["batch"], 144, g.final_swin_dim, device=dev)
+    else:
+        img = W.synth_images(w["batch"], g).to(dev)
     pipe(img)
     while pipe.outstanding():
         pipe.collect()
@@ -60,10 +65,14 @@ def report(path):
     busy = sum(k[1] - k[0] for k in chain) / 1e3
     print(f"one search alone: {len(chain)} launches, {total:.1f} us wall, {busy:.1f} us inside kernels, "
           f"{total - busy:.1f} us of gaps ({(total - busy) / max(1, len(chain) - 1):.2f} us per boundary)")
-    steps = [i for i, k in enumerate(chain) if "dec_embed" in k[2]]
-    mid = steps[len(steps) // 2]
-    nxt = steps[len(steps) // 2 + 1]
-    print(f"step {len(steps) // 2} of the search ({nxt - mid} launches, {(chain[nxt][0] - chain[mid][0]) / 1e3:.1f} us):")
+    gaps = sorted(((chain[i][0] - chain[i - 1][1]) / 1e3, i) for i in range(1, len(chain)))[-5:]
+    print("largest gaps (us, launch index): " + ", ".join(f"{g:.1f} @ {i}" for g, i in reversed(gaps)))
+    steps = [i + 1 for i, k in enumerate(chain[:-1]) if "beam_search_step" in k[2] or "beam_step_kernel" in k[2]]
+    steps = [1] + steps                                # (launch 0 is the reset; a step ends with the beam update)
+    which = min(int(os.environ.get("ODIC_STEP", len(steps) // 2)), len(steps) - 2)
+    mid = steps[which]
+    nxt = steps[which + 1]
+    print(f"step {which} of the search ({nxt - mid} launches, {(chain[nxt][0] - chain[mid][0]) / 1e3:.1f} us):")
     prev_end = chain[mid - 1][1]
     for k in chain[mid:nxt]:
         print(f"  gap {(k[0] - prev_end) / 1e3:6.2f} us | run {(k[1] - k[0]) / 1e3:6.2f} us | grid {k[3] // max(1, k[4]):5d} x {k[4]:4d} | {short(k[2])}")

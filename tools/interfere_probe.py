@@ -41,7 +41,7 @@ cands = {
     "cross_attn": lambda: ops.cross_attn_step(x, d, st.kv, st.kv.shape[2], 0, d, st.enc_len, st.row_valid, out_d, d, N,
                                               st.n_img, st.S, d, g.num_heads),
     # (the step advances *pos: re-arm the state every time, or the prefixes run past their T positions)
-    "full decode step": lambda: (ops.beam_reset(st.beam_state, st.n_img, st.beams, st.T, 79), pipe._step(0)),
+    "full decode step": lambda: (pipe._reset(0), pipe._step(0)),
 }
 s2 = torch.cuda.Stream()
 NL = 64
