@@ -15,6 +15,9 @@
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDP = BK + 1;
+#ifndef ODIC_SKINNY_MAXW
+#define ODIC_SKINNY_MAXW 16         // K-slices (= waves) per block of the one-row-tile-per-block decomposition
+#endif
 #ifndef ODIC_SKINNY_LDS_KIB
 #define ODIC_SKINNY_LDS_KIB 12      // stay below the ~16 KiB a CU has left beside the encode stream's GEMM blocks (sweep: 6→1420, 9→1455, 15→1448, 48→1430 captions/s)
 #endif
@@ -154,7 +157,9 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(Params p) {
 //      over 3x the CUs and the per-wave chain of dependent load rounds shrinks 3x (48x512x2048: 24 -> 11 us);
 //   2  three row tiles per WAVE (W fragments loaded once per block, 8 K-slices, 512-thread blocks that fit four to a
 //      CU): for the wide products (vocabulary, 625 column tiles) where shape 1 would be thousands of blocks.
-template <int MTW, int UN, bool FOLD, typename OutT, int MAXT>
+// ONE: the K-slice of a wave is a single round of loads (K/KS <= 16·UN) — no second register buffer, which is
+// what lets two or three of the 512-thread blocks of decomposition 2 share a CU.
+template <int MTW, int UN, bool FOLD, typename OutT, int MAXT, bool ONE>
 __global__ __launch_bounds__(MAXT) void gemm_f32_skinny_kernel(Params p, int kslice, int KS, int MT) {
   extern __shared__ float red[];                   // [KS][MT][4][64] partial tiles (+ [KS][MT*16][2] row sums if FOLD)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -184,7 +189,8 @@ __global__ __launch_bounds__(MAXT) void gemm_f32_skinny_kernel(Params p, int ksl
     am_ok[i] = m < p.M;
     arow[i] = A + (long)min(m, p.M - 1) * p.lda + 4 * fq;
   }
-  float4 w4[2][UN], a4[2][UN][MTW];
+  constexpr int NBUF = ONE ? 1 : 2;
+  float4 w4[NBUF][UN], a4[NBUF][UN][MTW];
   auto load_round = [&](int buf, int k) {            // addresses clamped, values masked in compute()
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -216,14 +222,16 @@ __global__ __launch_bounds__(MAXT) void gemm_f32_skinny_kernel(Params p, int ksl
     }
   };
   constexpr int STEP = 16 * UN;
-  if (t0 < MT && k_begin < k_end) {
+  if constexpr (ONE) {
+    if (t0 < MT && k_begin < k_end) { load_round(0, k_begin); compute(0, k_begin); }
+  } else if (t0 < MT && k_begin < k_end) {
     load_round(0, k_begin);
     for (int k = k_begin; k < k_end; k += 2 * STEP) {
-      if (k + STEP < k_end) load_round(1, k + STEP);
+      if (k + STEP < k_end) load_round(NBUF - 1, k + STEP);
       compute(0, k);
       if (k + STEP < k_end) {
         if (k + 2 * STEP < k_end) load_round(0, k + 2 * STEP);
-        compute(1, k + STEP);
+        compute(NBUF - 1, k + STEP);
       }
     }
   }
@@ -252,7 +260,19 @@ __global__ __launch_bounds__(MAXT) void gemm_f32_skinny_kernel(Params p, int ksl
   const float* bias = p.bias ? p.bias + bz * p.strideBias : nullptr;
   const float* resid = p.residual ? p.residual + bz * p.strideR : nullptr;
   OutT* out = (OutT*)p.out + bz * p.strideC;
-  const float inv_k = 1.0f / (float)p.K;
+  if constexpr (FOLD) {                              // row moments: combine the K-slices once per row, not per element
+    const float inv_k = 1.0f / (float)p.K;
+    float mean = 0.f, rstd = 0.f;
+    if (tid < MT * 16) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int w = 0; w < KS; ++w) { s1 += rsum[(w * MT * 16 + tid) * 2]; s2 += rsum[(w * MT * 16 + tid) * 2 + 1]; }
+      mean = s1 * inv_k;
+      rstd = rsqrtf(fmaxf(s2 * inv_k - mean * mean, 0.f) + p.ln_eps);
+    }
+    __syncthreads();
+    if (tid < MT * 16) { rsum[tid * 2] = mean; rsum[tid * 2 + 1] = rstd; }
+    __syncthreads();
+  }
   for (int e = tid; e < MT * 256; e += blockDim.x) {
     const int i = e >> 8, j = (e >> 6) & 3, l = e & 63;
     float v = 0.f;
@@ -262,11 +282,8 @@ __global__ __launch_bounds__(MAXT) void gemm_f32_skinny_kernel(Params p, int ksl
     if (row < p.M && col < p.N) {
       v *= p.alpha;
       if constexpr (FOLD) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int w = 0; w < KS; ++w) { s1 += rsum[((w * MT + i) * 16 + r16) * 2]; s2 += rsum[((w * MT + i) * 16 + r16) * 2 + 1]; }
-        const float mean = s1 * inv_k;
-        const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
-        v = (v - mean * p.ln_colsum[col]) * rsqrtf(var + p.ln_eps);
+        const float mean = rsum[(i * 16 + r16) * 2], rstd = rsum[(i * 16 + r16) * 2 + 1];
+        v = (v - mean * p.ln_colsum[col]) * rstd;
       }
       if (bias) v += p.bias_axis ? bias[row] : bias[col];
       v = apply_act<false>(v, p.act);
@@ -291,13 +308,17 @@ static void launch_skinny(const Params& p, int out_dtype, int batch, hipStream_t
   const size_t shmem = (size_t)(KS * MT * 256 + KS * MT * 32) * sizeof(float);
   const bool fold = p.ln_colsum != nullptr;
   constexpr int MAXT = 64 * MAXW;
+  const bool one = kslice <= 16 * UN;
+#define ODIC_SKINNY_GO(FOLD_, OUT_, ONE_)                                                                          \
+  hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, FOLD_, OUT_, MAXT, ONE_>), grid, block, shmem, stream, p, kslice, KS, MT)
   if (out_dtype == ODIC_BF16) {
-    if (fold) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, true, bf16_raw, MAXT>), grid, block, shmem, stream, p, kslice, KS, MT);
-    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, false, bf16_raw, MAXT>), grid, block, shmem, stream, p, kslice, KS, MT);
+    if (fold) { if (one) ODIC_SKINNY_GO(true, bf16_raw, true); else ODIC_SKINNY_GO(true, bf16_raw, false); }
+    else { if (one) ODIC_SKINNY_GO(false, bf16_raw, true); else ODIC_SKINNY_GO(false, bf16_raw, false); }
   } else {
-    if (fold) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, true, float, MAXT>), grid, block, shmem, stream, p, kslice, KS, MT);
-    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<MTW, UN, false, float, MAXT>), grid, block, shmem, stream, p, kslice, KS, MT);
+    if (fold) { if (one) ODIC_SKINNY_GO(true, float, true); else ODIC_SKINNY_GO(true, float, false); }
+    else { if (one) ODIC_SKINNY_GO(false, float, true); else ODIC_SKINNY_GO(false, float, false); }
   }
+#undef ODIC_SKINNY_GO
 }
 
 }  // namespace
@@ -316,12 +337,12 @@ int odic_gemm_f32_launch(const odic_gemm_args* a, hipStream_t stream) {
   const bool want_ln = a->ln_colsum != nullptr;
   const bool skinny_ok = p.vec_ok && a->M <= 192 && a->K % 16 == 0;
   if (want_ln && !(skinny_ok && a->bias_axis == 0)) return ODIC_EUNSUPPORTED;
-  if (skinny_ok && (a->N >= 64 || want_ln)) {
+  if (skinny_ok && (a->N >= 64 || want_ln) && !(a->tile_cfg == 3 && !want_ln)) {     // (3: the 64x64 tile kernel)
     const int mt = (a->M + 15) / 16, ct = (a->N + 15) / 16;
     int shape = a->tile_cfg;
     if (shape < 0 || shape > 2) shape = (long)ct * mt * a->batch <= 768 ? 1 : 2;
     if (shape == 1) {
-      launch_skinny<1, 4, 16>(p, a->out_dtype, a->batch, stream, mt, 16);
+      launch_skinny<1, 4, ODIC_SKINNY_MAXW>(p, a->out_dtype, a->batch, stream, mt, 16);
     } else if (shape == 2) {
       launch_skinny<3, 4, 8>(p, a->out_dtype, a->batch, stream, (mt + 2) / 3, 24);
     } else {

@@ -12,7 +12,8 @@ FAMILIES = {"gemm_bf16": r"gemm_bf16_", "gemm_f32": r"gemm_f32_", "gemm_fp8": r"
             "gemm_f16": r"gemm_lowp_nt_kernel<(\d+, ){6}2,", "layernorm": r"\blayernorm_kernel",
             "window_attention_bf16": r"window_attention_bf16", "patch_embed": r"patch_embed_kernel",
             "patch_merge_layernorm": r"layernorm_kernel<\d+, true", "cross_attn_step": r"cross_attn_step_kernel",
-            "dynexp_step": r"dynexp_", "logsoftmax_topk": r"logsoftmax_topk_kernel"}
+            "dynexp_step": r"dynexp_", "logsoftmax_topk": r"logsoftmax_topk_kernel",
+            "beam_search_step": r"beam_search_step_kernel"}
 
 
 def load(path, counter):

@@ -20,7 +20,7 @@ for N, K in ((512, 512), (2560, 512), (2048, 512), (512, 2048), (512, 1536), (10
     Wf, bf, cs = ops.fold_layernorm(W, b, torch.ones(K, device="cuda"), torch.zeros(K, device="cuda"))
     cells = []
     variants = []
-    for shp in (0, 1, 2):
+    for shp in (0, 1, 2, 3):
         variants.append((f"shape{shp}", lambda shp=shp: ops.gemm(A, W, b, out=out, tile_cfg=shp)))
     variants.append(("auto folded-LN", lambda: ops.gemm(A, Wf, bf, out=out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, ln_fold=(cs, 1e-5))))
     for name, fn in variants:
