@@ -79,12 +79,15 @@ struct DynParams {
   int N, T, d, E; float eps;
 };
 
-// One block per sequence, 512 threads.  Phase 1: cache writes, the 2t+E+1 dot products (one per 16-lane group,
+// One block per sequence, 1024 threads.  Phase 1: cache writes, the 2t+E+1 dot products (one per 16-lane group,
 // 32 in flight per block, float4 loads), the normalised forward / backward weights, and the coefficients of
-// the re-associated sum → LDS.  Phase 2 (one channel per thread): the sums over the cached value, condition and
-// bias rows — 3·(t+1) + E independent, coalesced loads per thread.
-__global__ __launch_bounds__(512) void dynexp_step_kernel(DynParams p) {
+// the re-associated sum → LDS.  Phase 2 (two threads per channel): the sums over the cached value, condition and
+// bias rows — (3·(t+1) + E) / 2 independent, coalesced loads per thread.
+constexpr int DYN_NT = 1024;         // threads per sequence: the step is a chain of dependent load rounds, so the
+                                     // block is as wide as it can be (64 dot-product groups, 2 x 512 channel threads)
+__global__ __launch_bounds__(DYN_NT) void dynexp_step_kernel(DynParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int NTD = DYN_NT;
   const int d = p.d, E = p.E, T = p.T, n = blockIdx.x, tid = threadIdx.x;
   const int t = *p.pos;
   float* cond_t = sm;                  // [d]
@@ -93,39 +96,40 @@ __global__ __launch_bounds__(512) void dynexp_step_kernel(DynParams p) {
   float* ck = dk + T;                  // [T]  cond_j·key_t
   float* qk_t = ck + T;                // [MAX_E]  qexp[e]·key_t
   float* nfw = qk_t + MAX_E;           // [2*MAX_E] 1/(Σ_j relu(±z_fw[e][·]) + eps)
-  float* red = nfw + 2 * MAX_E;        // [8]
-  int* slot = (int*)(red + 8);         // [T]
+  float* red = nfw + 2 * MAX_E;        // [16]
+  int* slot = (int*)(red + 16);        // [T]
   float* qkh = (float*)(slot + T);     // [T*E]  qexp[e]·key_j history
   float* wba = qkh + T * E;            // [T*E]  backward weights of this step
   float* wbb = wba + T * E;            // [T*E]
   float* scr = wbb + T * E;            // ca[T] | cb[T] | wja[T] | wjb[T] | wea[E] | web[E]
+  float* comb = scr + 4 * T + 2 * E;   // [NTD]  second half's partial sums of phase 2
 
   const float* lin = p.lin + (long)n * p.ldlin;
   const float inv_sqrt_d = rsqrtf((float)d);
   const long NT = (long)p.N;
   const int TE = T * E;
 
-  for (int c = tid; c < d; c += 512) {
+  for (int c = tid; c < d; c += NTD) {
     const float cv = lin[c], kv = lin[d + c];
     cond_t[c] = cv; key_t[c] = kv;
     const long o = ((long)t * NT + n) * d + c;
     p.cond_c[o] = cv; p.key_c[o] = kv; p.va_c[o] = lin[2 * d + c]; p.vb_c[o] = lin[3 * d + c];
   }
-  for (int j = tid; j <= t; j += 512) {
+  for (int j = tid; j <= t; j += NTD) {
     const int sl = j < t ? p.anc[(long)n * T + j] : n;
     slot[j] = sl;
   }
   __syncthreads();
-  for (int i = tid; i < t * E; i += 512) {
+  for (int i = tid; i < t * E; i += NTD) {
     const int j = i / E, e = i - j * E;
     qkh[i] = p.qk_c[((long)j * NT + slot[j]) * E + e];
   }
 
-  // dot products, one per 16-lane group:
+  // dot products, one per 16-lane group (64 groups):
   //   items 0..E-1: qk_t[e];  E..E+t: dk[j] (j = 0..t);  E+t+1 .. E+2t: ck[j] (j = 0..t-1)
   const int nitems = E + (t + 1) + t;
   const int grp = tid >> 4, gl = tid & 15;
-  for (int it = grp; it < nitems; it += 32) {
+  for (int it = grp; it < nitems; it += NTD / 16) {
     const float* a; const float* b;
     if (it < E) { a = p.qexp + (long)it * d; b = key_t; }
     else if (it < E + t + 1) {
@@ -153,18 +157,23 @@ __global__ __launch_bounds__(512) void dynexp_step_kernel(DynParams p) {
   if (tid == 0) ck[t] = dk[t];           // cond_t·key_t
   __syncthreads();
 
-  if (tid < E) {
-    float sp = 0.f, sn = 0.f;
-    for (int j = 0; j <= t; ++j) {
-      const float q = j < t ? qkh[j * E + tid] : qk_t[tid];
-      const float z = (q + dk[j]) * inv_sqrt_d;
-      sp += fmaxf(z, 0.f); sn += fmaxf(-z, 0.f);
+  // forward normalisers: 32 lanes per expansion query (E <= 32 → all of them in one pass), fixed shuffle order
+  {
+    const int e = tid >> 5, q = tid & 31;
+    if (e < E) {
+      float sp = 0.f, sn = 0.f;
+      for (int j = q; j <= t; j += 32) {
+        const float qq = j < t ? qkh[j * E + e] : qk_t[e];
+        const float z = (qq + dk[j]) * inv_sqrt_d;
+        sp += fmaxf(z, 0.f); sn += fmaxf(-z, 0.f);
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) { sp += __shfl_xor(sp, o, 64); sn += __shfl_xor(sn, o, 64); }
+      if (q == 0) { nfw[e] = 1.0f / (sp + p.eps); nfw[MAX_E + e] = 1.0f / (sn + p.eps); }
     }
-    nfw[tid] = 1.0f / (sp + p.eps);
-    nfw[MAX_E + tid] = 1.0f / (sn + p.eps);
   }
   float bp = 0.f, bn = 0.f;
-  for (int i = tid; i < (t + 1) * E; i += 512) {
+  for (int i = tid; i < (t + 1) * E; i += NTD) {
     const int j = i / E, e = i - j * E;
     const float z = (qk_t[e] + ck[j]) * inv_sqrt_d;
     bp += fmaxf(z, 0.f); bn += fmaxf(-z, 0.f);
@@ -176,7 +185,7 @@ __global__ __launch_bounds__(512) void dynexp_step_kernel(DynParams p) {
   // backward weights of this step → LDS
   float* wfa_t = p.wfa_c + ((long)t * NT + n) * TE;
   float* wfb_t = p.wfb_c + ((long)t * NT + n) * TE;
-  for (int i = tid; i < (t + 1) * E; i += 512) {
+  for (int i = tid; i < (t + 1) * E; i += NTD) {
     const int j = i / E, e = i - j * E;
     const float q = j < t ? qkh[i] : qk_t[e];
     const float zf = (q + dk[j]) * inv_sqrt_d;
@@ -187,67 +196,92 @@ __global__ __launch_bounds__(512) void dynexp_step_kernel(DynParams p) {
     wbb[i] = fmaxf(-zb, 0.f) * ibn;
   }
   __syncthreads();                        // (also orders the block's own wfa_t / wfb_t stores before the reads below)
-  // coefficients ca[i] = Σ_{j>=i} Σ_e wba[j][e]·wfa_j[i][e] (and cb): 4 lanes per key position i, lane q takes
-  // j = i+q, i+q+4, ...; fixed shuffle order → bit-identical run to run
-  for (int w = tid; w < 4 * (t + 1); w += 512) {
-    const int i = w >> 2, q = w & 3;
-    float sa = 0.f, sb = 0.f;
-    for (int j = i + q; j <= t; j += 4) {
-      const long row = ((long)j * NT + slot[j]) * TE + (long)i * E;
-      const float* fa = p.wfa_c + row;
-      const float* fb = p.wfb_c + row;
-      const float* ba = wba + j * E;
-      const float* bb = wbb + j * E;
-      for (int e = 0; e < E; e += 4) {
-        const float4 x = *(const float4*)(fa + e), y = *(const float4*)(fb + e);
-        sa = fmaf(ba[e], x.x, sa); sa = fmaf(ba[e + 1], x.y, sa); sa = fmaf(ba[e + 2], x.z, sa); sa = fmaf(ba[e + 3], x.w, sa);
-        sb = fmaf(bb[e], y.x, sb); sb = fmaf(bb[e + 1], y.y, sb); sb = fmaf(bb[e + 2], y.z, sb); sb = fmaf(bb[e + 3], y.w, sb);
+  // coefficients ca[i] = Σ_{j>=i} Σ_e wba[j][e]·wfa_j[i][e] (and cb): LP lanes per key position i (as many as the
+  // block has for t+1 keys, 4..32), lane q takes j = i+q, i+q+LP, ...; fixed shuffle order → bit-identical run to run
+  {
+    int LP = 4;
+    while (LP < 32 && (t + 1) * LP * 2 <= NTD) LP *= 2;
+    const int i = tid / LP, q = tid - i * LP;
+    if (i <= t) {
+      float sa = 0.f, sb = 0.f;
+      for (int j = i + q; j <= t; j += LP) {
+        const long row = ((long)j * NT + slot[j]) * TE + (long)i * E;
+        const float* fa = p.wfa_c + row;
+        const float* fb = p.wfb_c + row;
+        const float* ba = wba + j * E;
+        const float* bb = wbb + j * E;
+        for (int e = 0; e < E; e += 4) {
+          const float4 x = *(const float4*)(fa + e), y = *(const float4*)(fb + e);
+          sa = fmaf(ba[e], x.x, sa); sa = fmaf(ba[e + 1], x.y, sa); sa = fmaf(ba[e + 2], x.z, sa); sa = fmaf(ba[e + 3], x.w, sa);
+          sb = fmaf(bb[e], y.x, sb); sb = fmaf(bb[e + 1], y.y, sb); sb = fmaf(bb[e + 2], y.z, sb); sb = fmaf(bb[e + 3], y.w, sb);
+        }
       }
+      for (int o = 1; o < LP; o <<= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+      if (q == 0) { scr[i] = sa; scr[T + i] = sb; }
     }
-    sa += __shfl_xor(sa, 1, 64); sa += __shfl_xor(sa, 2, 64);
-    sb += __shfl_xor(sb, 1, 64); sb += __shfl_xor(sb, 2, 64);
-    if (q == 0) { scr[i] = sa; scr[T + i] = sb; }
   }
-  for (int j = tid; j <= t; j += 512) {           // wja[j] = Σ_e wba[j][e]
+  for (int j = tid; j <= t; j += NTD) {           // wja[j] = Σ_e wba[j][e]
     float sa = 0.f, sb = 0.f;
     for (int e = 0; e < E; ++e) { sa += wba[j * E + e]; sb += wbb[j * E + e]; }
     scr[2 * T + j] = sa; scr[3 * T + j] = sb;
   }
-  for (int e = tid; e < E; e += 512) {            // wea[e] = Σ_j wba[j][e]
-    float sa = 0.f, sb = 0.f;
-    for (int j = 0; j <= t; ++j) { sa += wba[j * E + e]; sb += wbb[j * E + e]; }
-    scr[4 * T + e] = sa; scr[4 * T + E + e] = sb;
+  {                                               // wea[e] = Σ_j wba[j][e]: 32 lanes per e
+    const int e = tid >> 5, q = tid & 31;
+    if (e < E) {
+      float sa = 0.f, sb = 0.f;
+      for (int j = q; j <= t; j += 32) { sa += wba[j * E + e]; sb += wbb[j * E + e]; }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+      if (q == 0) { scr[4 * T + e] = sa; scr[4 * T + E + e] = sb; }
+    }
   }
   __syncthreads();
 
-  // ---- phase 2
+  // ---- phase 2: thread (half h, channel c): half 0 sums the earlier positions and the first E/2 bias rows, half 1
+  //      the later ones; half 1's partial sums pass through LDS
   const float* ca = scr; const float* cb = scr + T;
   const float* wja = scr + 2 * T; const float* wjb = scr + 3 * T;
   const float* wea = scr + 4 * T; const float* web = wea + E;
   const bool valid = p.row_valid[n] != 0;
-  for (int c = tid; c < d; c += 512) {
+  constexpr int HALF = NTD / 2;
+  const int h = tid / HALF, cl = tid - h * HALF;
+  const int jm = (t + 1) / 2;
+  const int j0 = h ? jm : 0, j1 = h ? t : jm;       // positions [j0, j1) from the caches; half 1 also takes position t
+  const int e0 = h ? E / 2 : 0, e1 = h ? E : E / 2;
+  for (int cb0 = 0; cb0 < d; cb0 += HALF) {
+    const int c = cb0 + cl;
     float oa = 0.f, ob = 0.f;
+    if (c < d) {
+#pragma unroll 8
+      for (int j = j0; j < j1; ++j) {
+        const long o = ((long)j * NT + slot[j]) * d + c;
+        const float va = p.va_c[o], vb = p.vb_c[o], cj = p.cond_c[o];
+        oa = fmaf(ca[j], va, oa); oa = fmaf(wja[j], cj, oa);
+        ob = fmaf(cb[j], vb, ob); ob = fmaf(wjb[j], cj, ob);
+      }
+      if (h) {
+        oa = fmaf(ca[t], lin[2 * d + c], oa); oa = fmaf(wja[t], cond_t[c], oa);
+        ob = fmaf(cb[t], lin[3 * d + c], ob); ob = fmaf(wjb[t], cond_t[c], ob);
+      }
 #pragma unroll 4
-    for (int j = 0; j < t; ++j) {
-      const long o = ((long)j * NT + slot[j]) * d + c;
-      const float va = p.va_c[o], vb = p.vb_c[o], cj = p.cond_c[o];
-      oa = fmaf(ca[j], va, oa); oa = fmaf(wja[j], cj, oa);
-      ob = fmaf(cb[j], vb, ob); ob = fmaf(wjb[j], cj, ob);
+      for (int e = e0; e < e1; ++e) {
+        const float be = p.bexp[(long)e * d + c];
+        oa = fmaf(wea[e], be, oa);
+        ob = fmaf(web[e], be, ob);
+      }
     }
-    oa = fmaf(ca[t], lin[2 * d + c], oa); oa = fmaf(wja[t], cond_t[c], oa);
-    ob = fmaf(cb[t], lin[3 * d + c], ob); ob = fmaf(wjb[t], cond_t[c], ob);
-#pragma unroll 4
-    for (int e = 0; e < E; ++e) {
-      const float be = p.bexp[(long)e * d + c];
-      oa = fmaf(wea[e], be, oa);
-      ob = fmaf(web[e], be, ob);
+    if (h) { comb[cl] = oa; comb[HALF + cl] = ob; }
+    __syncthreads();
+    if (!h && c < d) {
+      oa += comb[cl]; ob += comb[HALF + cl];
+      float yv = p.y_in[(long)n * p.ldyi + c];
+      if (valid) {
+        const float sg = 1.0f / (1.0f + expf(-lin[4 * d + c]));
+        yv += sg * oa + (1.0f - sg) * ob;
+      }
+      p.y[(long)n * p.ldy + c] = yv;
     }
-    float yv = p.y_in[(long)n * p.ldyi + c];
-    if (valid) {
-      const float sg = 1.0f / (1.0f + expf(-lin[4 * d + c]));
-      yv += sg * oa + (1.0f - sg) * ob;
-    }
-    p.y[(long)n * p.ldy + c] = yv;
+    __syncthreads();
   }
 }
 
@@ -296,6 +330,12 @@ __global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __res
 #pragma unroll
   for (int b = 0; b < NB; ++b) valid[b] = row_valid[n0 + min(b, nb - 1)];
 
+  // V rows of the first P·V batch are requested now: their latency passes under the score and softmax phases
+  const int c = tid % dk, g = tid / dk, ng = 256 / dk;
+  const float* vp = kvb + voff + h * dk + c;
+  float vpre[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) vpre[i] = vp[(long)min(g + i * ng, S - 1) * ldkv];
   // ---- scores: wave w takes sweeps w, w+4, ...; up to 3 sweeps of K loads in flight
   const int nsweep = (S + kps - 1) / kps;
   for (int sw0 = wave; sw0 < nsweep; sw0 += 12) {
@@ -341,15 +381,17 @@ __global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __res
   }
   __syncthreads();
   // ---- P·V: thread = (channel c, key group g); groups take keys g, g + ng, ...
-  const int c = tid % dk, g = tid / dk, ng = 256 / dk;
   float acc[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) acc[b] = 0.f;
-  const float* vp = kvb + voff + h * dk + c;
   for (int s0 = g; s0 < S; s0 += 12 * ng) {
     float v[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) v[i] = vp[(long)min(s0 + i * ng, S - 1) * ldkv];
+    for (int i = 0; i < 12; ++i) v[i] = vpre[i];
+    if (s0 + 12 * ng < S) {                        // next batch in flight under this one's FMAs
+#pragma unroll
+      for (int i = 0; i < 12; ++i) vpre[i] = vp[(long)min(s0 + 12 * ng + i * ng, S - 1) * ldkv];
+    }
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       const int s = s0 + i * ng;
@@ -371,27 +413,43 @@ __global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-// One block (1024 threads) per row.  Pass 1: every thread keeps the top-KM of its strided slice in
-// registers (insertion into a static array) → the row max is the max of the heads.  Pass 2:
-// Σ exp(x - max).  Then k rounds of block arg-max over the thread heads; the winner pops its
-// head.  Ties → lower index (within a thread indices ascend, across threads compared explicitly).
+// log-softmax + exact top-k (ties → lower index) of up to NR rows AT ONCE by one 512-thread block (the fused search
+// step: the k logits rows of one image; the stand-alone kernel: NR = 1).  A thread holds a 20-value slice of every
+// row in registers (V <= 10240; longer rows stream).  Selection by threshold instead of sorting:
+//   1. wave maxima of every row → LDS (their maximum is the row maximum the log-sum-exp needs anyway);
+//   2. tau = the k-th largest of the 8 wave maxima: at least k elements are >= tau, so the k best all are;
+//   3. in the Σexp pass every element >= tau (k .. a dozen of them) is appended to a candidate list in LDS;
+//   4. wave r picks the k best of row r's candidates: k rounds of a wave arg-max over (value, lower index).
+// Per row that is ~60 VALU operations per thread and k+1 shuffle chains, against ~1000 for per-thread sorted lists
+// (which made a block that owns several rows ALU-bound).  Rows whose candidate list would overflow (k > 8 wave
+// maxima, or hundreds of equal values) take k rounds of a block-wide arg-max instead — exact, just slower.
+// `top_val` / `top_idx` ([row][k]) may point to global memory or LDS; logp0 (optional): the full log-prob rows.
 // ---------------------------------------------------------------------------------------------
-// Up to NR rows AT ONCE (the fused search step: the k logits rows of one image; the stand-alone kernel: NR = 1): every
-// reduction carries NR values, so the barrier count is that of a single row, and a row's arithmetic and its order
-// do not depend on NR — both users produce identical candidates.  `top_val` / `top_idx` ([row][k]) may point to global
-// memory or LDS (the fused step keeps the candidates on chip); logp0 (optional): the full log-prob rows (ldp).
-template <int NR> struct TopkSharedN { float red[NR][16]; float bv[NR][16]; int bi[NR][16]; int winner[NR]; };
+constexpr int TOPK_CAP = 128;          // candidates per row (two per lane of the selecting wave)
+template <int NR> struct TopkSharedN {
+  float red[NR][16]; float red2[NR][16]; int cnt[NR]; float cv[NR][TOPK_CAP]; int ci[NR][TOPK_CAP];
+  float bv[16]; int bi[16];
+};
 
-template <int KM, int NR, int NTH, bool NORM>
+__device__ __forceinline__ void wave_argmax(float& best, int& besti) {        // every lane ends with the winner
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+  }
+}
+
+template <int NR, int NTH, bool NORM>
 __device__ __forceinline__ void rows_logsoftmax_topk(const float* __restrict__ x0, long ldl, int nr,
                                                      float* __restrict__ logp0, long ldp, float* top_val,
                                                      int* top_idx, int V, int k, TopkSharedN<NR>& sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float tv[NR][KM]; int ti[NR][KM];
   constexpr int NPT = 10240 / NTH, NWV = NTH / 64;
   const bool small = V <= NPT * NTH;
-  float xv[NR][NPT];                       // V <= 10240: the thread's slice of every row stays in registers
-  if (small) {
+  float xv[NR][NPT];
+  float tm[NR];
+  if (small) {                                       // every row's loads are in flight before the first use
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const float* x = x0 + (long)min(r, nr - 1) * ldl;
@@ -401,78 +459,88 @@ __device__ __forceinline__ void rows_logsoftmax_topk(const float* __restrict__ x
   }
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
+    tm[r] = -INFINITY;
+    if (r < nr) {
+      if (small) {
 #pragma unroll
-    for (int q = 0; q < KM; ++q) { tv[r][q] = -INFINITY; ti[r][q] = 0x7fffffff; }
+        for (int u = 0; u < NPT; ++u) tm[r] = fmaxf(tm[r], xv[r][u]);
+      } else {
+        const float* x = x0 + (long)r * ldl;
+        for (int i = tid; i < V; i += NTH) tm[r] = fmaxf(tm[r], x[i]);
+      }
+    }
+  }
+  __syncthreads();                                   // (the previous call's readers of sh are done)
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const float m = wave_max(tm[r]);
+    if (lane == 0) sh.red[r][wave] = m;
+  }
+  if (tid < NR) sh.cnt[tid] = 0;
+  __syncthreads();
+  float mx[NR], tau[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    float wm[NWV];
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) wm[i] = sh.red[r][i];
+    float t = wm[0];
+#pragma unroll
+    for (int i = 1; i < NWV; ++i) t = fmaxf(t, wm[i]);
+    mx[r] = t;
+    tau[r] = -INFINITY;                              // k > NWV: every element is a candidate → the overflow path
+    if (k <= NWV) {
+#pragma unroll
+      for (int i = 0; i < NWV; ++i) {                // the element with exactly k-1 others ranked above it
+        int above = 0;
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) above += (wm[j] > wm[i] || (wm[j] == wm[i] && j < i)) ? 1 : 0;
+        if (above == k - 1) tau[r] = wm[i];
+      }
+    }
+  }
+  // Σ exp(x - max) and the candidates
+  float sm[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    float sacc = 0.f;
     if (r < nr) {
       const float* x = x0 + (long)r * ldl;
       if (small) {
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
-          float v = xv[r][u]; int vi = tid + u * NTH;
-          if (v > tv[r][KM - 1]) {
-#pragma unroll
-            for (int q = 0; q < KM; ++q) {
-              if (v > tv[r][q]) { const float fv = tv[r][q]; const int fi = ti[r][q]; tv[r][q] = v; ti[r][q] = vi; v = fv; vi = fi; }
-            }
+          const float v = xv[r][u];
+          if constexpr (NORM) sacc += expf(v - mx[r]);
+          if (v >= tau[r] && tid + u * NTH < V) {
+            const int pos = atomicAdd(&sh.cnt[r], 1);
+            if (pos < TOPK_CAP) { sh.cv[r][pos] = v; sh.ci[r][pos] = tid + u * NTH; }
           }
         }
       } else {
         for (int i = tid; i < V; i += NTH) {
-          float v = x[i]; int vi = i;
-          if (v > tv[r][KM - 1]) {
-#pragma unroll
-            for (int q = 0; q < KM; ++q) {
-              if (v > tv[r][q]) { const float fv = tv[r][q]; const int fi = ti[r][q]; tv[r][q] = v; ti[r][q] = vi; v = fv; vi = fi; }
-            }
+          const float v = x[i];
+          if constexpr (NORM) sacc += expf(v - mx[r]);
+          if (v >= tau[r]) {
+            const int pos = atomicAdd(&sh.cnt[r], 1);
+            if (pos < TOPK_CAP) { sh.cv[r][pos] = v; sh.ci[r][pos] = i; }
           }
         }
       }
     }
+    sm[r] = wave_sum(sacc);
   }
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+    if (lane == 0) sh.red2[r][wave] = sm[r];
+  __syncthreads();
   float lse[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) lse[r] = 0.f;                     // NORM = false: rows are log-probs already
-  if constexpr (NORM) {
-    // row maxima
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const float m = wave_max(tv[r][0]);
-      if (lane == 0) sh.red[r][wave] = m;
-    }
-    __syncthreads();
-    float mx[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      float t = sh.red[r][0];
-      for (int i = 1; i < NWV; ++i) t = fmaxf(t, sh.red[r][i]);
-      mx[r] = t;
-    }
-    // Σ exp(x - max)
-    float sm[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      float sacc = 0.f;
-      if (r < nr) {
-        const float* x = x0 + (long)r * ldl;
-        if (small) {
-#pragma unroll
-          for (int u = 0; u < NPT; ++u) sacc += expf(xv[r][u] - mx[r]);
-        } else {
-          for (int i = tid; i < V; i += NTH) sacc += expf(x[i] - mx[r]);
-        }
-      }
-      sm[r] = wave_sum(sacc);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-      if (lane == 0) sh.red[r][wave] = sm[r];
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
+  for (int r = 0; r < NR; ++r) {
+    lse[r] = 0.f;                                    // NORM = false: rows are log-probs already
+    if constexpr (NORM) {
       float t = 0.f;
-      for (int i = 0; i < NWV; ++i) t += sh.red[r][i];
+#pragma unroll
+      for (int i = 0; i < NWV; ++i) t += sh.red2[r][i];
       lse[r] = mx[r] + logf(t);
     }
   }
@@ -482,52 +550,63 @@ __device__ __forceinline__ void rows_logsoftmax_topk(const float* __restrict__ x
       if (r < nr)
         for (int i = tid; i < V; i += NTH) logp0[(long)r * ldp + i] = x0[(long)r * ldl + i] - lse[r];
   }
-  for (int rd = 0; rd < k; ++rd) {
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      float best = tv[r][0]; int besti = ti[r][0];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(besti, o, 64);
-        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-      }
-      if (lane == 0) { sh.bv[r][wave] = best; sh.bi[r][wave] = besti; }
-    }
-    __syncthreads();
-    if (tid < nr) {
-      const int r = tid;
-      float bb = sh.bv[r][0]; int ix = sh.bi[r][0];
-      for (int w = 1; w < NWV; ++w)
-        if (sh.bv[r][w] > bb || (sh.bv[r][w] == bb && sh.bi[r][w] < ix)) { bb = sh.bv[r][w]; ix = sh.bi[r][w]; }
-      sh.winner[r] = ix;
+  // selection: wave r takes row r
+  if (wave < nr) {
+    const int r = wave, n = sh.cnt[r];
+    if (n <= TOPK_CAP) {
       float l = lse[0];
 #pragma unroll
       for (int q = 1; q < NR; ++q) if (r == q) l = lse[q];
-      top_val[r * k + rd] = bb - l;
-      top_idx[r * k + rd] = ix;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      if (ti[r][0] == sh.winner[r] && r < nr) {
-#pragma unroll
-        for (int q = 0; q + 1 < KM; ++q) { tv[r][q] = tv[r][q + 1]; ti[r][q] = ti[r][q + 1]; }
-        tv[r][KM - 1] = -INFINITY; ti[r][KM - 1] = 0x7fffffff;
+      float c0 = -INFINITY, c1 = -INFINITY; int i0 = 0x7fffffff, i1 = 0x7fffffff;
+      if (lane < n) { c0 = sh.cv[r][lane]; i0 = sh.ci[r][lane]; }
+      if (lane + 64 < n) { c1 = sh.cv[r][lane + 64]; i1 = sh.ci[r][lane + 64]; }
+      for (int rd = 0; rd < k; ++rd) {
+        const bool first = c0 > c1 || (c0 == c1 && i0 < i1);
+        float best = first ? c0 : c1; int besti = first ? i0 : i1;
+        wave_argmax(best, besti);
+        if (lane == 0) { top_val[r * k + rd] = best - l; top_idx[r * k + rd] = besti; }
+        if (i0 == besti) { c0 = -INFINITY; i0 = 0x7fffffff; }
+        if (i1 == besti) { c1 = -INFINITY; i1 = 0x7fffffff; }
       }
     }
   }
+  // overflowed rows (block-uniform): k rounds of a block-wide arg-max over the elements ranked below the last winner
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    if (r < nr && sh.cnt[r] > TOPK_CAP) {
+      const float* x = x0 + (long)r * ldl;
+      float pv = INFINITY; int pi = -1;              // last winner: later rounds take (value, index) ranked after it
+      for (int rd = 0; rd < k; ++rd) {
+        float best = -INFINITY; int besti = 0x7fffffff;
+        for (int i = tid; i < V; i += NTH) {
+          const float v = x[i];
+          const bool after = v < pv || (v == pv && i > pi);
+          if (after && (v > best || (v == best && i < besti))) { best = v; besti = i; }
+        }
+        wave_argmax(best, besti);
+        __syncthreads();
+        if (lane == 0) { sh.bv[wave] = best; sh.bi[wave] = besti; }
+        __syncthreads();
+        best = sh.bv[0]; besti = sh.bi[0];
+        for (int w = 1; w < NWV; ++w)
+          if (sh.bv[w] > best || (sh.bv[w] == best && sh.bi[w] < besti)) { best = sh.bv[w]; besti = sh.bi[w]; }
+        if (tid == 0) { top_val[r * k + rd] = best - lse[r]; top_idx[r * k + rd] = besti; }
+        pv = best; pi = besti;
+      }
+    }
+  }
+  __syncthreads();
 }
 
-template <int KM, bool NORM = true>
+template <bool NORM = true>
 __global__ __launch_bounds__(512) void logsoftmax_topk_kernel(const float* __restrict__ logits, long ldl,
                                                               float* __restrict__ logp_out, long ldp,
                                                               float* __restrict__ top_val, int* __restrict__ top_idx,
                                                               int V, int k) {
   __shared__ TopkSharedN<1> sh;
   const int n = blockIdx.x;
-  rows_logsoftmax_topk<KM, 1, 512, NORM>(logits + (long)n * ldl, ldl, 1, logp_out ? logp_out + (long)n * ldp : nullptr, ldp,
-                                         top_val + (long)n * k, top_idx + (long)n * k, V, k, sh);
+  rows_logsoftmax_topk<1, 512, NORM>(logits + (long)n * ldl, ldl, 1, logp_out ? logp_out + (long)n * ldp : nullptr, ldp,
+                                     top_val + (long)n * k, top_idx + (long)n * k, V, k, sh);
 }
 
 
@@ -810,7 +889,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamParams p, EmbedArgs e
 
 // The whole tail of a search step in one launch: log-softmax + top-k of the image's k logits rows, NR rows per pass
 // (the candidates stay in LDS), the beam update above and the next position's input embedding.
-template <int KM, int NR>
+template <int NR>
 __global__ __launch_bounds__(512) void beam_search_step_kernel(const float* __restrict__ logits, long ldl, int V,
                                                                 BeamParams p, EmbedArgs e) {
   __shared__ BeamShared s;
@@ -820,7 +899,7 @@ __global__ __launch_bounds__(512) void beam_search_step_kernel(const float* __re
   if (t + 1 >= p.T) return;
   const int nrows = t == 0 ? 1 : k;     // at the first position only beam 0 seeds the search
   for (int r0 = 0; r0 < nrows; r0 += NR)
-    rows_logsoftmax_topk<KM, NR, 512, true>(logits + (long)(b * k + r0) * ldl, ldl, min(NR, nrows - r0), nullptr, 0, s.cv + r0 * k,
+    rows_logsoftmax_topk<NR, 512, true>(logits + (long)(b * k + r0) * ldl, ldl, min(NR, nrows - r0), nullptr, 0, s.cv + r0 * k,
                                  s.ci + r0 * k, V, k, sh);
   beam_update<512>(p, e, s, b, t);
 }
@@ -904,10 +983,10 @@ extern "C" int odic_dynexp_step(const float* lin, int64_t ldlin, const float* qe
   p.vb_c = vb_c; p.wfa_c = wfa_c; p.wfb_c = wfb_c; p.qk_c = qk_c; p.anc = anc; p.row_valid = row_valid;
   p.pos = pos; p.y_in = y_in; p.ldyi = ldy_in; p.y = y; p.ldy = ldy;
   p.N = N; p.T = T; p.d = d; p.E = E; p.eps = eps;
-  const size_t shmem = (size_t)(2 * d + 2 * T + 3 * MAX_E + 8 + 3 * T * E + 4 * T + 2 * E) * sizeof(float) +
+  const size_t shmem = (size_t)(2 * d + 2 * T + 3 * MAX_E + 16 + 3 * T * E + 4 * T + 2 * E + DYN_NT) * sizeof(float) +
                        (size_t)T * sizeof(int);
   if (shmem > 64 * 1024) return ODIC_EINVAL;
-  hipLaunchKernelGGL(dynexp_step_kernel, dim3(N), dim3(512), shmem, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(dynexp_step_kernel, dim3(N), dim3(DYN_NT), shmem, (hipStream_t)stream, p);
   return odic_launch_status();
 }
 
@@ -982,9 +1061,7 @@ extern "C" int odic_topk_rows(const float* logp, int64_t ldl, float* top_val, in
   if (!logp || !top_val || !top_idx) return ODIC_ENULL;
   if (N <= 0 || V <= 0 || k <= 0 || k > MAX_K || k > V) return ODIC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (k <= 4) hipLaunchKernelGGL((logsoftmax_topk_kernel<4, false>), dim3(N), dim3(512), 0, s, logp, (long)ldl, (float*)nullptr, 0L, top_val, top_idx, V, k);
-  else if (k <= 8) hipLaunchKernelGGL((logsoftmax_topk_kernel<8, false>), dim3(N), dim3(512), 0, s, logp, (long)ldl, (float*)nullptr, 0L, top_val, top_idx, V, k);
-  else hipLaunchKernelGGL((logsoftmax_topk_kernel<16, false>), dim3(N), dim3(512), 0, s, logp, (long)ldl, (float*)nullptr, 0L, top_val, top_idx, V, k);
+  hipLaunchKernelGGL(logsoftmax_topk_kernel<false>, dim3(N), dim3(512), 0, s, logp, (long)ldl, (float*)nullptr, 0L, top_val, top_idx, V, k);
   return odic_launch_status();
 }
 
@@ -993,9 +1070,7 @@ extern "C" int odic_logsoftmax_topk(const float* logits, int64_t ldl, float* log
   if (!logits || !top_val || !top_idx) return ODIC_ENULL;
   if (N <= 0 || V <= 0 || k <= 0 || k > MAX_K || k > V) return ODIC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (k <= 4) hipLaunchKernelGGL(logsoftmax_topk_kernel<4>, dim3(N), dim3(512), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
-  else if (k <= 8) hipLaunchKernelGGL(logsoftmax_topk_kernel<8>, dim3(N), dim3(512), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
-  else hipLaunchKernelGGL(logsoftmax_topk_kernel<16>, dim3(N), dim3(512), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
+  hipLaunchKernelGGL(logsoftmax_topk_kernel<true>, dim3(N), dim3(512), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
   return odic_launch_status();
 }
 
@@ -1042,12 +1117,10 @@ extern "C" int odic_beam_search_step(const float* logits, int64_t ldl, int32_t V
   if (rc != 0) return rc;
   if (V <= 0 || beams > V) return ODIC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  // (per-thread top-list length >= beams, rows per pass): 512-thread blocks, so that a thread's 20-value slice of
-  // every row of the pass and its top lists fit the 256 registers without spilling
-  if (beams <= 4) hipLaunchKernelGGL((beam_search_step_kernel<4, 4>), dim3(n_img), dim3(512), 0, s, logits, (long)ldl, V, p, e);
-  else if (beams == 5) hipLaunchKernelGGL((beam_search_step_kernel<5, 5>), dim3(n_img), dim3(512), 0, s, logits, (long)ldl, V, p, e);
-  else if (beams <= 8) hipLaunchKernelGGL((beam_search_step_kernel<8, 4>), dim3(n_img), dim3(512), 0, s, logits, (long)ldl, V, p, e);
-  else hipLaunchKernelGGL((beam_search_step_kernel<16, 2>), dim3(n_img), dim3(512), 0, s, logits, (long)ldl, V, p, e);
+  // rows per pass: a thread's 20-value slice of every row of the pass lives in registers
+  if (beams <= 3) hipLaunchKernelGGL(beam_search_step_kernel<3>, dim3(n_img), dim3(512), 0, s, logits, (long)ldl, V, p, e);
+  else if (beams <= 5) hipLaunchKernelGGL(beam_search_step_kernel<5>, dim3(n_img), dim3(512), 0, s, logits, (long)ldl, V, p, e);
+  else hipLaunchKernelGGL(beam_search_step_kernel<6>, dim3(n_img), dim3(512), 0, s, logits, (long)ldl, V, p, e);
   return odic_launch_status();
 }
 

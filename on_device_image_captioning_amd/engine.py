@@ -442,8 +442,15 @@ class CaptionerEngine:
             ops.gemm(ops.layernorm(pre, self.drn_w, self.drn_b), self.voc_w, self.voc_b, out=st.logits)
 
     def beam_step(self, st: DecodeState, eos_idx: int) -> None:
-        """One full search step: decoder → log-softmax / top-k / beam bookkeeping / next input, the tail as ONE
-        launch.  The state must have been armed with ops.beam_reset(st.beam_state, ..., emb=st.emb)."""
+        """One full search step: decoder → log-softmax / top-k (one block per row) → beam bookkeeping + the next
+        position's input rows (one block per image).  The state must have been armed with
+        ops.beam_reset(st.beam_state, ..., emb=st.emb).  (odic_beam_search_step does the two launches in one, but a
+        block per image then works through its k rows alone: 20 / 30 us against 14 / 16 at beam 3 / 5,
+        tools/topk_bench.py.)"""
         self.step_logits(st, embed=False)
         V = self.g.vocab_size
-        ops.beam_search_step(st.logits, V, V, st.beam_state, st.n_img, st.beams, st.T, eos_idx, emb=st.emb)
+        if os.environ.get("ODIC_FUSED_SEARCH_STEP", "0") == "1":
+            ops.beam_search_step(st.logits, V, V, st.beam_state, st.n_img, st.beams, st.T, eos_idx, emb=st.emb)
+            return
+        ops.logsoftmax_topk(st.logits, V, None, 0, st.cand_val, st.cand_idx, st.N, V, st.beams)
+        ops.beam_step(st.cand_val, st.cand_idx, st.beam_state, st.n_img, st.beams, st.T, eos_idx, emb=st.emb)

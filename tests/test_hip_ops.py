@@ -274,6 +274,29 @@ def test_logsoftmax_topk(ops):
     assert_close(tv, wv, 2e-6, "topk values")
 
 
+@pytest.mark.parametrize("V,k", [(10000, 3), (10000, 8), (10000, 12), (37, 5), (12000, 4), (513, 16)])
+def test_logsoftmax_topk_threshold_selection_edge_cases(ops, V, k):
+    """The top-k is chosen among the elements >= the k-th largest wave maximum (decoder_ops.hip); rows on which that
+    candidate list overflows — all-equal rows, hundreds of exact ties at the top, k above the wave count — and rows
+    shorter than a block take the block-wide path: indices and values must still be exactly torch's stable order
+    (value descending, lower index first), for streamed rows (V > 10240) as well."""
+    g = torch.Generator().manual_seed(5)
+    rows = [torch.randn(V, generator=g) * 2.0,                                   # ordinary
+            torch.zeros(V),                                                      # all equal → indices 0..k-1
+            torch.randn(V, generator=g).round(),                                 # a coarse grid: many ties everywhere
+            torch.where(torch.rand(V, generator=g) < 0.5, torch.tensor(4.0), torch.randn(V, generator=g))]  # half the row tied at the top
+    rows[0][V - 1] = rows[0][0] = rows[0].max() + 1.0                            # tie between the first and the last element
+    x = torch.stack(rows)
+    N = x.shape[0]
+    want = torch.log_softmax(x.double(), -1)
+    order = torch.argsort(x.double(), dim=-1, descending=True, stable=True)[:, :k]
+    tv = torch.empty(N, k, device="cuda")
+    ti = torch.empty(N, k, dtype=torch.int32, device="cuda")
+    ops.logsoftmax_topk(dev(x), V, None, 0, tv, ti, N, V, k)
+    assert torch.equal(ti.cpu().long(), order), (ti.cpu(), order)
+    assert_close(tv, torch.gather(want, 1, order), 3e-6, "topk values")
+
+
 def test_ensemble_logprobs_and_topk_rows(ops):
     # log(mean_m softmax(logits_m)) and its row-wise top-k (ties → lower index), the two ensemble-step kernels
     N, V, M, k = 7, 10000, 3, 5
