@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--fp32-steps", type=int, default=10)
     ap.add_argument("--cpu-runs", type=int, default=6)
     ap.add_argument("--decode-lanes", type=int, default=2)
+    ap.add_argument("--decode-cus", type=int, default=None,
+                    help="compute units reserved for the decode lanes (CU-masked streams); 0 = shared chip")
     ap.add_argument("--encode-lanes", type=int, default=1,
                     help="encode graphs (one batch each) that may run concurrently on their own HIP streams")
     ap.add_argument("--decode-group", type=int, default=1,
@@ -181,7 +183,8 @@ def build_model(device, precision, workload):
 def make_pipe(model, a):
     from on_device_image_captioning_amd.pipeline import CaptionPipeline
     return CaptionPipeline(model, a.batch, a.beam, a.max_len, SOS, EOS, use_graphs=not a.no_graphs,
-                           decode_lanes=a.decode_lanes, decode_group=a.decode_group, encode_lanes=a.encode_lanes)
+                           decode_lanes=a.decode_lanes, decode_group=a.decode_group, encode_lanes=a.encode_lanes,
+                           decode_cus=a.decode_cus)
 
 
 def roofline_pass(pipe, images):
@@ -444,7 +447,7 @@ def main():
                        "backbone_precision": a.precision if e2e else None, "encoder_precision": a.precision,
                        "decoder_precision": "fp32",
                        "hip_graphs": not a.no_graphs, "parallelism": f"image-shard x{world}",
-                       "caption_len_check": min(len(c) for c in caps), "encode_lanes": pipe.E, "decode_lanes": pipe.D,
+                       "caption_len_check": min(len(c) for c in caps), "encode_lanes": pipe.E, "decode_lanes": pipe.D, "decode_cus": a.decode_cus or 0,
                        "decode_group_batches": pipe.G,
                        "overlap": "encode graph of batch i+1 || beam-search step graphs of earlier batches, one HIP stream each"},
         }

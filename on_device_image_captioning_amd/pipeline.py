@@ -41,7 +41,8 @@ class CaptionPipeline:
 
     def __init__(self, model: CaptioningModel, batch: int, beam_size: int, max_seq_len: int, sos_idx: int,
                  eos_idx: int, use_graphs: bool = True, done_poll: int = 0, decode_lanes: int = 2,
-                 streams=None, decode_group: int = 1, encode_lanes: int = 1, feat_len: int = 144):
+                 streams=None, decode_group: int = 1, encode_lanes: int = 1, feat_len: int = 144,
+                 decode_cus: Optional[int] = None):
         """done_poll = 0: never look at the `done` flag (fixed work per batch — benchmark mode with
         weights that never emit EOS); n > 0: host checks every n steps and stops early.
         `model` is an End_ExpansionNet_v2 (inputs: images [B,3,H,W]) or a features-only ExpansionNet_v2
@@ -100,6 +101,9 @@ class CaptionPipeline:
         if streams is not None:                                    # ([encode streams], [decode streams]) supplied by the caller
             self.s_encs = list(streams[0]) if isinstance(streams[0], (list, tuple)) else [streams[0]]
             self.s_dec = list(streams[1])
+        elif decode_cus:                                           # the decode lanes on compute units of their own
+            from .cu_streams import split_streams
+            self.s_encs, self.s_dec = split_streams(dv, decode_cus, self.E, self.D)
         else:
             self.s_encs = [torch.cuda.Stream(device=dv) for _ in range(self.E)]
             self.s_dec = [torch.cuda.Stream(device=dv) for _ in range(self.D)]
