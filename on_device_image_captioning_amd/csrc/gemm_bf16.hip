@@ -47,6 +47,7 @@ struct Params {
   //             rstd·(A·W'ᵀ − mean·colsum) + bias' = LayerNorm(A)·Wᵀ + bias (W', colsum, bias' packed by the caller).
   bf16_raw* out16; long ld16; float* stats_out;
   const float* ln_stats; const float* ln_colsum; float ln_eps;
+  int skew_from, skew_to, skew_sleeps;   // blocks [skew_from, skew_to) start skew_sleeps x 64·127 clocks late
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -89,6 +90,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && MI * NI == 32) ?
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / NWN, wn = wave % NWN;
   ODIC_ENCODE_PRIO();
+  if ((int)blockIdx.x >= p.skew_from && (int)blockIdx.x < p.skew_to)
+    for (int i = 0; i < p.skew_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+
 
   // XCD x = blockIdx % 8 owns tile rows [r0,r1) x cols [c0,c1); inside the rectangle tiles run N-fastest
   int tm, tn;
@@ -948,6 +952,7 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
   if (((uintptr_t)a->A & 15) || ((uintptr_t)a->W & 15)) return ODIC_EINVAL;
   if ((a->strideA % 8) || (a->strideW % 8)) return ODIC_EINVAL;
   Params p;
+  p.skew_from = 0; p.skew_to = 0; p.skew_sleeps = 0;
   p.A = (const bf16_raw*)a->A; p.W = (const bf16_raw*)a->W; p.bias = a->bias; p.residual = a->residual;
   p.out = a->out; p.M = a->M; p.N = a->N; p.K = a->K;
   p.lda = a->lda; p.ldw = a->ldw; p.ldr = a->ldr; p.ldc = a->ldc;
@@ -1000,6 +1005,13 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     case 29: return launch_cfg<2, 2, 4, 8, 3, 32>(p, a->out_dtype, a->batch, stream); // 128 x 256 x 32, 3 stages (72 KiB)
     case 30: return launch_cfg<2, 2, 8, 4, 2, 32>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32, 2 stages (48 KiB)
     case 31: return launch_cfg<2, 2, 8, 4, 2, 64>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 64, 2 stages (96 KiB)
+    // 32 / 33: config 10 with the blocks that become the SECOND resident block of a CU (ids 256..511) started 8 / 12 us
+    // late, so that the two blocks of a CU are out of phase — one's pipeline fill and store tail under the other's
+    // K-loop — instead of running prologue, loop and epilogue in lockstep (fc1 / fc2 of stage 2: -5 %)
+    case 32: p.skew_from = 256; p.skew_to = 512; p.skew_sleeps = 2;
+             return launch_cfg<4, 2, 4, 4, 3, 32, true>(p, a->out_dtype, a->batch, stream);
+    case 33: p.skew_from = 256; p.skew_to = 512; p.skew_sleeps = 3;
+             return launch_cfg<4, 2, 4, 4, 3, 32, true>(p, a->out_dtype, a->batch, stream);
     case 12: if (p.out16 || p.ln_stats) return ODIC_EUNSUPPORTED;
              return launch_256sq(p, a->out_dtype, a->batch, stream);                 // 256 x 256 x 64, 4 phases per K-tile (128 KiB)
     // 16 + c: tile config c as a persistent, dynamically scheduled launch (needs args->workspace, batch == 1)

@@ -403,7 +403,7 @@ def test_gemm_bf16_256sq_phase_pipeline(ops):
 PERSISTENT_CFGS = [16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27]
 
 
-@pytest.mark.parametrize("cfg", list(range(12)) + [13, 14, 15, 28, 29, 30, 31] + PERSISTENT_CFGS)
+@pytest.mark.parametrize("cfg", list(range(12)) + [13, 14, 15, 28, 29, 30, 31, 32, 33] + PERSISTENT_CFGS)
 def test_gemm_bf16_every_tile_config(ops, cfg):
     """Each tile / pipeline-depth / BK instantiation — one block per tile (0..11) and persistent with dynamic tile
     scheduling (16 + c) — against fp64 on ragged shapes (M, N not multiples of any tile) with every epilogue
