@@ -446,6 +446,9 @@ __device__ __forceinline__ void rows_logsoftmax_topk(const float* __restrict__ x
                                                      int* top_idx, int V, int k, TopkSharedN<NR>& sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NPT = 10240 / NTH, NWV = NTH / 64;
+  const bool force_wide = ((k >> 8) & 1) != 0;       // (diagnosis) take the block-wide selection for every row
+  if ((k >> 9) & 1) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }    // (diagnosis) read the rows late
+  k &= 0xff;
   const bool small = V <= NPT * NTH;
   float xv[NR][NPT];
   float tm[NR];
@@ -489,7 +492,7 @@ __device__ __forceinline__ void rows_logsoftmax_topk(const float* __restrict__ x
     for (int i = 1; i < NWV; ++i) t = fmaxf(t, wm[i]);
     mx[r] = t;
     tau[r] = -INFINITY;                              // k > NWV: every element is a candidate → the overflow path
-    if (k <= NWV) {
+    if (k <= NWV && !force_wide) {
 #pragma unroll
       for (int i = 0; i < NWV; ++i) {                // the element with exactly k-1 others ranked above it
         int above = 0;
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(512) void logsoftmax_topk_kernel(const float* __res
   __shared__ TopkSharedN<1> sh;
   const int n = blockIdx.x;
   rows_logsoftmax_topk<1, 512, NORM>(logits + (long)n * ldl, ldl, 1, logp_out ? logp_out + (long)n * ldp : nullptr, ldp,
-                                     top_val + (long)n * k, top_idx + (long)n * k, V, k, sh);
+                                     top_val + (long)n * (k & 0xff), top_idx + (long)n * (k & 0xff), V, k, sh);
 }
 
 
@@ -1070,7 +1073,13 @@ extern "C" int odic_logsoftmax_topk(const float* logits, int64_t ldl, float* log
   if (!logits || !top_val || !top_idx) return ODIC_ENULL;
   if (N <= 0 || V <= 0 || k <= 0 || k > MAX_K || k > V) return ODIC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(logsoftmax_topk_kernel<true>, dim3(N), dim3(512), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k);
+  static int force = -1;
+  if (force < 0) {
+    const char* e = getenv("ODIC_TOPK_FORCE_WIDE");
+    const char* dl = getenv("ODIC_TOPK_DELAY");
+    force = ((e && e[0] == '1') ? 1 : 0) | ((dl && dl[0] == '1') ? 2 : 0);
+  }
+  hipLaunchKernelGGL(logsoftmax_topk_kernel<true>, dim3(N), dim3(512), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k | (force << 8));
   return odic_launch_status();
 }
 

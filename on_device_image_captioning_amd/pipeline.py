@@ -17,6 +17,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import ops
@@ -131,6 +133,8 @@ class CaptionPipeline:
         # step reads its position from device memory, so a graph of `chunk` steps serves any part of the search (a
         # graph-to-graph boundary costs 8.5 us on the decode stream, a node-to-node boundary nothing measurable)
         self.chunk = self.steps if not done_poll else max(1, min(done_poll, self.steps))
+        if os.environ.get("ODIC_STEP_CHUNK"):                    # measurement switch: steps per graph launch
+            self.chunk = max(1, min(int(os.environ["ODIC_STEP_CHUNK"]), self.steps))
         self.g_tail: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.D     # steps % chunk
         if use_graphs:
             self._capture()

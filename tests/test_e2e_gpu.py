@@ -327,6 +327,24 @@ def test_pipeline_decode_groups_match_reference(group, lanes, poll):
     assert pipe(flip) == want[::-1]                     # a lone batch: group of one real + repeats
 
 
+def test_pipeline_on_cu_masked_streams_gives_the_same_captions():
+    """decode_cus=R: the decode lanes on compute units 0..R-1 of the mask numbering, the encode stream on the
+    others (hipExtStreamCreateWithCUMask; an operating-point option, off by default) — captions unchanged."""
+    from on_device_image_captioning_amd.pipeline import CaptionPipeline
+    g = W.TINY
+    m = build_model("TINY", "eos")
+    store = np.load(os.path.join(GOLDEN, "tiny_eos.npz"))
+    want = [per[0] for per in unpad(store["beam3_T12.tokens"])]
+    img = W.synth_images(3, g).to(DEV)
+    pipe = CaptionPipeline(m, 3, 3, 12, TSOS, TEOS, decode_cus=32)
+    pipe.submit(img)
+    pipe.submit(img.flip(0).contiguous())
+    pipe.submit(img)
+    assert pipe.collect() == want
+    assert pipe.collect() == want[::-1]
+    assert pipe.collect() == want
+
+
 # ----------------------------------------------------------------------------------------- F3: sampling
 def test_sampling_mode_logprobs_are_teacher_forced_logprobs():
     """mode='sampling' draws tokens with the device RNG (not reproducible against the reference's CPU

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Determinism stress of the bench-shape pipeline: the captions of N sweeps of four distinct batches through
+CaptionPipeline (three in flight) against the un-pipelined direct calls, and the direct calls against themselves.
+
+    python tools/pipeline_stress.py [sweeps] [variant] [precision]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from on_device_image_captioning_amd import weights as W
+from on_device_image_captioning_amd.End_ExpansionNet_v2 import End_ExpansionNet_v2, make_drop_args
+from on_device_image_captioning_amd.pipeline import CaptionPipeline
+
+SOS, EOS = 79, 77
+sweeps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+variant = sys.argv[2] if len(sys.argv) > 2 else "eos"
+precision = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+torch.set_grad_enabled(False)
+dev = torch.device("cuda", 0)
+g = W.FULL
+sd = W.synth_state_dict(g, variant=variant, eos_idx=EOS)
+m = End_ExpansionNet_v2(**g.model_kwargs(), output_word2idx={i: i for i in range(g.vocab_size)},
+                        output_idx2word=list(range(g.vocab_size)), drop_args=make_drop_args(), rank=dev)
+m.load_state_dict(sd, strict=True)
+m.to(dev).eval().set_precision(precision)
+batches = [W.synth_images(16, g, seed=3000 + i).to(dev) for i in range(4)]
+
+
+def direct(b):
+    toks, _ = m(enc_x=b, enc_x_num_pads=[0] * 16, mode="beam_search", beam_size=3, how_many_outputs=1,
+                beam_max_seq_len=20, sample_or_max="max", sos_idx=SOS, eos_idx=EOS)
+    return [t[0] for t in toks]
+
+
+pipe = CaptionPipeline(m, 16, 3, 20, SOS, EOS, decode_lanes=int(os.environ.get("ODIC_LANES", "2")))
+want = [direct(b) for b in batches]
+bad_direct = 0
+for _ in range(3):
+    for i, b in enumerate(batches):
+        if direct(b) != want[i]:
+            bad_direct += 1
+print(f"direct calls repeated 3x: {bad_direct} batches differ from the first run")
+bad = 0
+for s in range(sweeps):
+    order = list(range(4)) if s % 2 == 0 else list(range(3, -1, -1))
+    got = []
+    for i in order:
+        while pipe.full():
+            got.append(pipe.collect())
+        pipe.submit(batches[i])
+    while pipe.outstanding():
+        got.append(pipe.collect())
+    for i, caps in zip(order, got):
+        for n, (a, b) in enumerate(zip(caps, want[i])):
+            if a != b:
+                bad += 1
+                pos = next(k for k in range(min(len(a), len(b))) if a[k] != b[k]) if a[:len(b)] != b[:len(a)] or len(a) != len(b) else -1
+                print(f"sweep {s}: batch {i} image {n} differs from position {pos} (lens {len(a)} / {len(b)})", flush=True)
+print(f"{sweeps} sweeps x 64 captions: {bad} captions differ from the direct call")
