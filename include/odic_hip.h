@@ -117,6 +117,10 @@ int odic_gemm(const odic_gemm_args* args, void* stream);
 int odic_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, void* out,
                    int32_t M, int32_t C, float eps, int32_t out_dtype, void* stream);
 
+/* Device-to-device copy of nbytes (a multiple of 16; both pointers 16-byte aligned) by a kernel of this library:
+ * the pipeline's K/V hand-off from the encode stream's staging buffer to a decode lane. */
+int odic_copy(const void* src, void* dst, int64_t nbytes, void* stream);
+
 /* Row-strided fp32 → bf16 conversion (feeds fp32 residual streams / caller tensors to the bf16 MFMA
  * GEMM).  x fp32 [M,C] (ldx) → out bf16 [M,C] (ldo); C, ldx, ldo multiples of 4. */
 int odic_cast_f32_to_bf16(const float* x, int64_t ldx, void* out, int64_t ldo, int32_t M, int32_t C,

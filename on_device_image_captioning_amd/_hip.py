@@ -62,6 +62,7 @@ _SIGNATURES = {
     "odic_window_attention": (C.c_int, [_P, _P, _P, _P] + [_I32] * 6 + [_F, _I32, _P]),
     "odic_stcexp_normalize": (C.c_int, [_P, _P, _P, _I32, _P, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _I32, _P]),
     "odic_selector_mix": (C.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _P]),
+    "odic_copy": (C.c_int, [_P, _P, _I64, _P]),
     "odic_dec_embed": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
     "odic_dynexp_step": (C.c_int, [_P, _I64, _P, _P] + [_P] * 7 + [_P, _P, _P, _P, _I64, _P, _I64] + [_I32] * 4 + [_F, _P]),
     "odic_cross_attn_step": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P, _P, _P, _I64] + [_I32] * 5 + [_P]),

@@ -83,7 +83,10 @@ struct DynParams {
 // 32 in flight per block, float4 loads), the normalised forward / backward weights, and the coefficients of
 // the re-associated sum → LDS.  Phase 2 (two threads per channel): the sums over the cached value, condition and
 // bias rows — (3·(t+1) + E) / 2 independent, coalesced loads per thread.
-constexpr int DYN_NT = 1024;         // threads per sequence: the step is a chain of dependent load rounds, so the
+#ifndef ODIC_DYN_NT
+#define ODIC_DYN_NT 1024
+#endif
+constexpr int DYN_NT = ODIC_DYN_NT;         // threads per sequence: the step is a chain of dependent load rounds, so the
                                      // block is as wide as it can be (64 dot-product groups, 2 x 512 channel threads)
 __global__ __launch_bounds__(DYN_NT) void dynexp_step_kernel(DynParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -330,12 +333,6 @@ __global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __res
 #pragma unroll
   for (int b = 0; b < NB; ++b) valid[b] = row_valid[n0 + min(b, nb - 1)];
 
-  // V rows of the first P·V batch are requested now: their latency passes under the score and softmax phases
-  const int c = tid % dk, g = tid / dk, ng = 256 / dk;
-  const float* vp = kvb + voff + h * dk + c;
-  float vpre[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) vpre[i] = vp[(long)min(g + i * ng, S - 1) * ldkv];
   // ---- scores: wave w takes sweeps w, w+4, ...; up to 3 sweeps of K loads in flight
   const int nsweep = (S + kps - 1) / kps;
   for (int sw0 = wave; sw0 < nsweep; sw0 += 12) {
@@ -381,17 +378,15 @@ __global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __res
   }
   __syncthreads();
   // ---- P·V: thread = (channel c, key group g); groups take keys g, g + ng, ...
+  const int c = tid % dk, g = tid / dk, ng = 256 / dk;
   float acc[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+  const float* vp = kvb + voff + h * dk + c;
   for (int s0 = g; s0 < S; s0 += 12 * ng) {
     float v[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) v[i] = vpre[i];
-    if (s0 + 12 * ng < S) {                        // next batch in flight under this one's FMAs
-#pragma unroll
-      for (int i = 0; i < 12; ++i) vpre[i] = vp[(long)min(s0 + 12 * ng + i * ng, S - 1) * ldkv];
-    }
+    for (int i = 0; i < 12; ++i) v[i] = vp[(long)min(s0 + i * ng, S - 1) * ldkv];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       const int s = s0 + i * ng;
@@ -446,9 +441,6 @@ __device__ __forceinline__ void rows_logsoftmax_topk(const float* __restrict__ x
                                                      int* top_idx, int V, int k, TopkSharedN<NR>& sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NPT = 10240 / NTH, NWV = NTH / 64;
-  const bool force_wide = ((k >> 8) & 1) != 0;       // (diagnosis) take the block-wide selection for every row
-  if ((k >> 9) & 1) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }    // (diagnosis) read the rows late
-  k &= 0xff;
   const bool small = V <= NPT * NTH;
   float xv[NR][NPT];
   float tm[NR];
@@ -492,7 +484,7 @@ __device__ __forceinline__ void rows_logsoftmax_topk(const float* __restrict__ x
     for (int i = 1; i < NWV; ++i) t = fmaxf(t, wm[i]);
     mx[r] = t;
     tau[r] = -INFINITY;                              // k > NWV: every element is a candidate → the overflow path
-    if (k <= NWV && !force_wide) {
+    if (k <= NWV) {
 #pragma unroll
       for (int i = 0; i < NWV; ++i) {                // the element with exactly k-1 others ranked above it
         int above = 0;
@@ -609,7 +601,7 @@ __global__ __launch_bounds__(512) void logsoftmax_topk_kernel(const float* __res
   __shared__ TopkSharedN<1> sh;
   const int n = blockIdx.x;
   rows_logsoftmax_topk<1, 512, NORM>(logits + (long)n * ldl, ldl, 1, logp_out ? logp_out + (long)n * ldp : nullptr, ldp,
-                                     top_val + (long)n * (k & 0xff), top_idx + (long)n * (k & 0xff), V, k, sh);
+                                     top_val + (long)n * k, top_idx + (long)n * k, V, k, sh);
 }
 
 
@@ -1072,14 +1064,8 @@ extern "C" int odic_logsoftmax_topk(const float* logits, int64_t ldl, float* log
                                     int32_t* top_idx, int32_t N, int32_t V, int32_t k, void* stream) {
   if (!logits || !top_val || !top_idx) return ODIC_ENULL;
   if (N <= 0 || V <= 0 || k <= 0 || k > MAX_K || k > V) return ODIC_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  static int force = -1;
-  if (force < 0) {
-    const char* e = getenv("ODIC_TOPK_FORCE_WIDE");
-    const char* dl = getenv("ODIC_TOPK_DELAY");
-    force = ((e && e[0] == '1') ? 1 : 0) | ((dl && dl[0] == '1') ? 2 : 0);
-  }
-  hipLaunchKernelGGL(logsoftmax_topk_kernel<true>, dim3(N), dim3(512), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k | (force << 8));
+  hipLaunchKernelGGL(logsoftmax_topk_kernel<true>, dim3(N), dim3(512), 0, (hipStream_t)stream, logits, (long)ldl, logp_out,
+                     (long)ldp, top_val, top_idx, V, k);
   return odic_launch_status();
 }
 

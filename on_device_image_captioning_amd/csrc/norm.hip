@@ -228,7 +228,23 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   *(ushort4*)(out + r * ldo + c) = pk;
 }
 
+// plain copy of 16-byte units, grid-stride (the K/V hand-off of the pipeline: the consumer kernels then read what a
+// kernel of this library wrote, under the same launch-boundary ordering as every other hand-off)
+__global__ __launch_bounds__(256) void copy16_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long n16) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+
 }  // namespace
+
+extern "C" int odic_copy(const void* src, void* dst, int64_t nbytes, void* stream) {
+  if (!src || !dst) return ODIC_ENULL;
+  if (nbytes <= 0 || (nbytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return ODIC_EINVAL;
+  const long n16 = nbytes / 16;
+  const long want = (n16 + 255) / 256;
+  hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)src, (float4*)dst, n16);
+  return odic_launch_status();
+}
 
 extern "C" int odic_cast_f32_to_bf16(const float* x, int64_t ldx, void* out, int64_t ldo, int32_t M, int32_t C,
                                      void* stream) {

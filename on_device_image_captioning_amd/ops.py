@@ -303,6 +303,17 @@ def cast_bf16(x: torch.Tensor, *, M: Optional[int] = None, C_: Optional[int] = N
     return out
 
 
+def copy(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst ← src (contiguous, same shape and dtype, a multiple of 16 bytes) by a kernel of this library."""
+    _need_cuda(src, dst)
+    if src.shape != dst.shape or src.dtype != dst.dtype or not src.is_contiguous() or not dst.is_contiguous():
+        raise RuntimeError("copy: contiguous tensors of one shape and dtype expected")
+    nbytes = src.numel() * src.element_size()
+    with _timed("copy", 0.0, 2.0 * nbytes):
+        _hip.check(_hip.load().odic_copy(_p(src), _p(dst), nbytes, _stream()), "odic_copy")
+    return dst
+
+
 def patch_merge_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, res: int, Cin: int,
                           *, eps: float = 1e-5, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
     _need_cuda(x, gamma, beta)

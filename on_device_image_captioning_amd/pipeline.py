@@ -266,7 +266,7 @@ class CaptionPipeline:
         sd = self.s_dec[lane]
         with torch.cuda.stream(sd):
             sd.wait_event(self.ev_enc[e])
-            self.kv[lane][:, gpos * self.B:(gpos + 1) * self.B].copy_(self.kv_stages[e])
+            self._hand_over(self.kv_stages[e], self.kv[lane][:, gpos * self.B:(gpos + 1) * self.B])
             if self.swin is None:
                 self.enc_len_grps[lane][gpos * self.B:(gpos + 1) * self.B].copy_(self.enc_lens[e])
             self.ev_kv_taken[e].record()
@@ -275,6 +275,14 @@ class CaptionPipeline:
         self._gfill += 1
         if self._gfill == self.G:
             self._launch_group()
+
+    @staticmethod
+    def _hand_over(src: torch.Tensor, dst: torch.Tensor) -> None:
+        """K/V of a batch from the encode stream's staging buffer into the lane's buffer (current stream)."""
+        if os.environ.get("ODIC_HANDOVER", "kernel") == "runtime" or not (src.is_contiguous() and dst.is_contiguous()):
+            dst.copy_(src)                                       # hipMemcpyAsync (blit kernel of the runtime)
+        else:
+            ops.copy(src, dst)
 
     def _len_host_free(self, e: int) -> None:
         self.ev_len_up[e].synchronize()                          # the previous upload from this pinned buffer is done

@@ -60,3 +60,63 @@ for s in range(sweeps):
                 pos = next(k for k in range(min(len(a), len(b))) if a[k] != b[k]) if a[:len(b)] != b[:len(a)] or len(a) != len(b) else -1
                 print(f"sweep {s}: batch {i} image {n} differs from position {pos} (lens {len(a)} / {len(b)})", flush=True)
 print(f"{sweeps} sweeps x 64 captions: {bad} captions differ from the direct call")
+
+
+def full_state(b, all_steps=True):
+    """the un-pipelined search of batch b, every step run (no early stop), returning the whole beam state"""
+    from on_device_image_captioning_amd import ops
+    eng = m._captioner_engine()
+    mem = m.forward_enc(b, [0] * 16)
+    st = eng.new_state(16, 3, 20, eng.project_kv(mem), m._enc_lens(16, mem.shape[1], [0] * 16))
+    ops.beam_reset(st.beam_state, 16, 3, 20, SOS, emb=st.emb)
+    for t in range(19):
+        eng.beam_step(st, EOS)
+    torch.cuda.synchronize()
+    return st
+
+
+if os.environ.get("ODIC_INSPECT") == "1":
+    found = 0
+    for s in range(int(os.environ.get("ODIC_INSPECT_SWEEPS", "1500"))):
+        order = [0, 1, 2, 3] if s % 2 == 0 else [3, 2, 1, 0]
+        got = []
+        for i in order:
+            while pipe.full():
+                got.append(pipe.collect())
+            pipe.submit(batches[i])
+        while pipe.outstanding():
+            got.append(pipe.collect())
+        torch.cuda.synchronize()
+        for pos_in_sweep in (2, 3):                     # their lane states are still intact
+            i = order[pos_in_sweep]
+            if got[pos_in_sweep] != want[i]:
+                lane = pos_in_sweep % 2
+                st = pipe.states[lane]
+                ref = full_state(batches[i])
+                found += 1
+                print(f"sweep {s}: batch {i} on lane {lane} differs; comparing the beam states")
+                kp, kr = pipe.kv[lane][0].float(), ref.kv.float()
+                dk = (kp - kr).abs()
+                nz = (dk > 0).nonzero()
+                print(f"  K/V the lane searched vs K/V of the un-pipelined encode: {int((dk > 0).sum())} of {dk.numel()} elements differ, "
+                      f"max |diff| {float(dk.max()):.3e}; shape {tuple(kp.shape)}")
+                if nz.numel():
+                    imgs_ = sorted(set(nz[:, 0].tolist())); toks_ = sorted(set(nz[:, 1].tolist()))
+                    cols_ = nz[:, 2]
+                    print(f"  images {imgs_[:16]} tokens {toks_[:24]}{'...' if len(toks_) > 24 else ''} columns {int(cols_.min())}..{int(cols_.max())} "
+                          f"({len(set((cols_ // 32).tolist()))} distinct 32-column groups)")
+                tp, tr = st.tokens.cpu(), ref.tokens.cpu()
+                lp, lr = st.logprobs.cpu(), ref.logprobs.cpu()
+                for im in range(0):
+                    if not torch.equal(tp[im], tr[im]) or not torch.equal(lp[im], lr[im]):
+                        print(f"  image {im}: n_elem pipe {st.n_elem.view(16, 3)[im].tolist()} ref {ref.n_elem.view(16, 3)[im].tolist()} "
+                              f"has_eos {st.has_eos.view(16, 3)[im].tolist()} / {ref.has_eos.view(16, 3)[im].tolist()}")
+                        for bm in range(3):
+                            print(f"    beam {bm} pipe tok {tp[im, bm].tolist()}")
+                            print(f"    beam {bm} ref  tok {tr[im, bm].tolist()}")
+                            print(f"    beam {bm} pipe lp  {[round(x, 4) for x in lp[im, bm].tolist()]}")
+                            print(f"    beam {bm} ref  lp  {[round(x, 4) for x in lr[im, bm].tolist()]}")
+                sys.stdout.flush()
+        if found >= 2:
+            break
+    print(f"inspect: {found} differing batches examined")
