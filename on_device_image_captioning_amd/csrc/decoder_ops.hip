@@ -870,16 +870,16 @@ __device__ __forceinline__ void beam_update(const BeamParams& p, const EmbedArgs
   }
 }
 
-__global__ __launch_bounds__(64) void beam_step_kernel(BeamParams p, EmbedArgs e) {
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p, EmbedArgs e) {
   __shared__ BeamShared s;
   const int b = blockIdx.x, k = p.k;
   const int t = *p.pos;                 // position just processed; prefix length is t+1
   if (t + 1 >= p.T) return;             // the prefix is full: a replay past the last step changes nothing
-  for (int i = threadIdx.x; i < k * k; i += 64) {
+  for (int i = threadIdx.x; i < k * k; i += 256) {
     s.cv[i] = p.cand_val[(long)b * k * k + i];
     s.ci[i] = p.cand_idx[(long)b * k * k + i];
   }
-  beam_update<64>(p, e, s, b, t);
+  beam_update<256>(p, e, s, b, t);       // (four waves: the k·d embedding rows and the prefix re-gather are the bulk)
 }
 
 // The whole tail of a search step in one launch: log-softmax + top-k of the image's k logits rows, NR rows per pass
@@ -1099,7 +1099,7 @@ extern "C" int odic_beam_step(const float* cand_val, const int32_t* cand_idx, co
   const int rc = beam_params(p, e, st, emb, n_img, beams, T, eos_idx);
   if (rc != 0) return rc;
   p.cand_val = cand_val; p.cand_idx = cand_idx;
-  hipLaunchKernelGGL(beam_step_kernel, dim3(n_img), dim3(64), 0, (hipStream_t)stream, p, e);
+  hipLaunchKernelGGL(beam_step_kernel, dim3(n_img), dim3(256), 0, (hipStream_t)stream, p, e);
   return odic_launch_status();
 }
 
