@@ -64,6 +64,7 @@ def test_argument_validation_needs_no_gpu(lib):
     emb = _hip.EmbedArgs(16, 16, None, 512, 512, 1.0)              # embedding tail asked for without an output
     assert lib.odic_beam_step(16, 16, ctypes.byref(st), ctypes.byref(emb), 4, 3, 20, 77, None) == -2
     assert lib.odic_beam_reset(None, None, 4, 3, 20, 79, None) == -2
+    assert lib.odic_copy(16, 32, 24, None) == -1 and lib.odic_copy(None, 32, 32, None) == -2
     assert lib.odic_beam_finalize_best(ctypes.byref(st), 16, 16, None, 16, 4, 3, 20, 77, None) == -2
     assert lib.odic_logsoftmax_sample(16, 8, None, 0, 16, 16, 4, 8, 9, 0, None, None) == -1           # k > V
     # persistent bf16 tile configurations need the caller's workspace

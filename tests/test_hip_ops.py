@@ -117,6 +117,21 @@ def test_gemm_f32_skinny_wave_splits(ops, M, N, K, shape):
     assert_close(got, want, 2e-5, "gemm_f32 skinny")
 
 
+def test_copy_kernel(ops):
+    # odic_copy: the pipeline's K/V hand-off (any dtype, 16-byte multiples; misuse is rejected, not truncated)
+    src = torch.randn(3, 144, 3072, device="cuda")
+    dst = torch.zeros_like(src)
+    assert ops.copy(src, dst) is dst and torch.equal(src, dst)
+    s16 = torch.arange(4096, device="cuda", dtype=torch.int32).bfloat16()
+    d16 = torch.zeros_like(s16)
+    ops.copy(s16, d16)
+    assert torch.equal(s16, d16)
+    with pytest.raises(RuntimeError):
+        ops.copy(src, torch.zeros(3, 144, 3071, device="cuda"))
+    with pytest.raises(RuntimeError):
+        ops.copy(torch.zeros(6, device="cuda"), torch.zeros(6, device="cuda"))      # 24 bytes
+
+
 # ------------------------------------------------------------------------------------------ GEMM bf16
 def test_gemm_bf16_identity_asymmetric(ops):
     # A = I, asymmetric small-integer W: out must equal Wᵀ exactly (catches any fragment / C-layout swap)
