@@ -15,6 +15,7 @@ from on_device_image_captioning_amd.End_ExpansionNet_v2 import End_ExpansionNet_
 from on_device_image_captioning_amd.pipeline import CaptionPipeline
 
 SOS, EOS = 79, 77
+BEAM, MAXLEN = int(os.environ.get("ODIC_BEAM", "3")), int(os.environ.get("ODIC_MAXLEN", "20"))
 sweeps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 variant = sys.argv[2] if len(sys.argv) > 2 else "eos"
 precision = sys.argv[3] if len(sys.argv) > 3 else "bf16"
@@ -30,12 +31,12 @@ batches = [W.synth_images(16, g, seed=3000 + i).to(dev) for i in range(4)]
 
 
 def direct(b):
-    toks, _ = m(enc_x=b, enc_x_num_pads=[0] * 16, mode="beam_search", beam_size=3, how_many_outputs=1,
-                beam_max_seq_len=20, sample_or_max="max", sos_idx=SOS, eos_idx=EOS)
+    toks, _ = m(enc_x=b, enc_x_num_pads=[0] * 16, mode="beam_search", beam_size=BEAM, how_many_outputs=1,
+                beam_max_seq_len=MAXLEN, sample_or_max="max", sos_idx=SOS, eos_idx=EOS)
     return [t[0] for t in toks]
 
 
-pipe = CaptionPipeline(m, 16, 3, 20, SOS, EOS, decode_lanes=int(os.environ.get("ODIC_LANES", "2")))
+pipe = CaptionPipeline(m, 16, BEAM, MAXLEN, SOS, EOS, decode_lanes=int(os.environ.get("ODIC_LANES", "2")))
 want = [direct(b) for b in batches]
 bad_direct = 0
 for _ in range(3):
