@@ -299,11 +299,8 @@ __global__ __launch_bounds__(DYN_NT) void dynexp_step_kernel(DynParams p) {
 //            NB accumulators; key groups combined through LDS.
 // kv: [n_img, S, ldkv], K at koff, V at voff.
 // ---------------------------------------------------------------------------------------------
-// (second launch bound: at most 128 registers, four waves per SIMD.  Not a speed choice — round 2 met a variant of this
-//  kernel at 131 registers that was bit-reproducible alone and gave rare wrong rows beside the encoder, and the same
-//  code capped at 128 registers did not: DESIGN.md §5)
 template <int NB>
-__global__ __launch_bounds__(256, 4) void cross_attn_step_kernel(const float* __restrict__ q, long ldq,
+__global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __restrict__ q, long ldq,
                                                               const float* __restrict__ kv, long ldkv, int koff,
                                                               int voff, const int* __restrict__ enc_len,
                                                               const int* __restrict__ row_valid,
