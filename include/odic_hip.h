@@ -17,7 +17,13 @@
  *     hipError_t of a failed launch.  Nothing is printed.
  *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
  *   - dtype codes: ODIC_F32 = 0 (float), ODIC_BF16 = 1 (bfloat16, raw uint16 storage), ODIC_FP8 = 2 (OCP e4m3,
- *     raw uint8), ODIC_F16 = 3 (IEEE half).
+ *     raw uint8), ODIC_F16 = 3 (IEEE half), ODIC_H2 = 4 (split fp16, see below).
+ *   - ODIC_H2 ("split fp16": the operand format of the near-exact fast mode): a value x is carried as hi + lo with
+ *     hi = fp16(x), lo = fp16(x - hi) — 22 significand bits — and a contraction runs as three fp16 MFMAs
+ *     (hi·hi + hi·lo + lo·hi, fp32 accumulate).  Storage is 4 bytes per element, so shapes, leading dimensions and
+ *     strides (in ELEMENTS) are those of the fp32 tensor it replaces; inside a row, every group of 8 consecutive
+ *     elements is 32 bytes: [8 x hi | 8 x lo].  Rows start on 32-byte boundaries (base 32-byte aligned, ld % 8 == 0).
+ *     All-zero bytes are the value 0, so zero-filled K padding is valid.  |x| saturates at 65504.
  */
 #ifndef ODIC_HIP_H
 #define ODIC_HIP_H
@@ -32,6 +38,7 @@ extern "C" {
 #define ODIC_BF16 1
 #define ODIC_FP8 2     /* OCP e4m3 (e4m3fn), one byte per element: the low-precision backbone mode's GEMM operands */
 #define ODIC_F16 3     /* IEEE half: that mode's qkv / attention activations */
+#define ODIC_H2 4      /* split fp16 (hi + lo pairs, 4 bytes per element): the near-exact fast mode's operands */
 
 #define ODIC_ACT_NONE 0
 #define ODIC_ACT_GELU 1    /* exact erf GELU (nn.GELU, swin_transformer_mod.py:87) */
@@ -43,7 +50,7 @@ extern "C" {
 #define ODIC_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ODIC_ABI_VERSION 12
+#define ODIC_ABI_VERSION 13
 int odic_abi_version(void);
 
 /* Human-readable build string ("gfx950 hipcc ..."), static storage. */
@@ -64,6 +71,9 @@ const char* odic_build_info(void);
  *   fp32 accumulate, out = cast(act(alpha·col_scale[n]·(A·Wᵀ) + bias)·out_scale) + residual with out_dtype in
  *   {ODIC_F32, ODIC_F16, ODIC_FP8}; K a multiple of 64 (fp8) / 32 (f16); batch == 1.  The caller quantises: W per
  *   output channel at pack time, A per tensor with a static scale — col_scale[n] is their product.
+ * in_dtype ODIC_H2 (near-exact fast mode): A and W are split-fp16 tensors, three MFMA 16x16x32 f16 per step into one
+ *   fp32 accumulator; out_dtype ODIC_F32 or ODIC_H2; exact-erf GELU; K % 32 == 0, lda / ldw / strides % 8 == 0,
+ *   32-byte aligned operands; any batch.  Weights may be pre-scaled by a power of two at pack time (undone in alpha).
  * ------------------------------------------------------------------------------------------- */
 typedef struct odic_gemm_args {
   const void* A; const void* W; const float* bias; const float* residual; void* out;
@@ -109,8 +119,8 @@ int odic_gemm(const odic_gemm_args* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps inside sqrt, biased variance — torch.nn.LayerNorm).
- *   x fp32 [M,C] (ldx) → out `out_dtype` [M,C] contiguous (ODIC_F32 / ODIC_BF16 / ODIC_FP8; an fp8 consumer's
- *   quantisation scale is folded into gamma / beta by the caller).   C % 4 == 0, C <= 8192.
+ *   x fp32 [M,C] (ldx) → out `out_dtype` [M,C] contiguous (ODIC_F32 / ODIC_BF16 / ODIC_FP8 / ODIC_H2; an fp8 consumer's
+ *   quantisation scale is folded into gamma / beta by the caller).   C % 4 == 0 (ODIC_H2: % 8), C <= 8192.
  * Replaces swin_transformer_mod.py:309,338 (norm1/norm2), :639 (final norm), layers.py:119,121,
  * 225,228,232 and the reduce norms End_ExpansionNet_v2.py:99,135.
  * ------------------------------------------------------------------------------------------- */
@@ -125,10 +135,12 @@ int odic_copy(const void* src, void* dst, int64_t nbytes, void* stream);
  * GEMM).  x fp32 [M,C] (ldx) → out bf16 [M,C] (ldo); C, ldx, ldo multiples of 4. */
 int odic_cast_f32_to_bf16(const float* x, int64_t ldx, void* out, int64_t ldo, int32_t M, int32_t C,
                           void* stream);
+/* The same into split fp16 (ODIC_H2): C % 8 == 0, ldo % 8 == 0 (elements of 4 bytes), out 32-byte aligned. */
+int odic_cast_f32_to_h2(const float* x, int64_t ldx, void* out, int64_t ldo, int32_t M, int32_t C, void* stream);
 
 /* PatchMerging gather + LayerNorm(4C)  (swin_transformer_mod.py:386-395):
- *   x fp32 [B, res*res, C] → out `out_dtype` [B, (res/2)², 4C]; channel blocks in the order
- *   (0,0),(1,0),(0,1),(1,1) of the 2x2 neighbourhood (row offset, col offset). */
+ *   x fp32 [B, res*res, C] → out `out_dtype` (ODIC_F32 / ODIC_BF16 / ODIC_H2) [B, (res/2)², 4C]; channel blocks in
+ *   the order (0,0),(1,0),(0,1),(1,1) of the 2x2 neighbourhood (row offset, col offset). */
 int odic_patch_merge_layernorm(const float* x, const float* gamma, const float* beta, void* out,
                                int32_t B, int32_t res, int32_t C, float eps, int32_t out_dtype,
                                void* stream);
@@ -172,6 +184,8 @@ int odic_resize_bilinear_normalize(const uint8_t* src_rgb, int32_t H, int32_t W,
  *   out  `dtype` [B*res*res, C]    softmax(q·kᵀ·scale + bias + mask)·v, heads concatenated,
  *        written back at the un-shifted token positions (ready for the proj Linear).
  * head_dim is 32 (every Swin-L stage), ws*ws <= 144, res % ws == 0, 0 <= shift < ws.
+ * dtype ODIC_H2 (near-exact fast mode; needs bias_shifted_prescaled, ws = 12): qkv and out are split-fp16 tensors,
+ *        q·kᵀ and P·v run as three fp16 MFMAs each, the softmax between them in fp32.
  * ------------------------------------------------------------------------------------------- */
 int odic_window_attention(const void* qkv, const float* bias_table, const float* bias_shifted_prescaled,
                           void* out, int32_t B, int32_t res, int32_t C, int32_t heads, int32_t ws,
@@ -186,15 +200,19 @@ int odic_window_attention(const void* qkv, const float* bias_table, const float*
  *   bw:  relu(±zᵀ), each of the `ngroups` column groups L1-normalised separately (layers.py:67-79)
  *        and pre-divided by ngroups (:84-85) → pos_bw, neg_bw `out_dtype` [B, S, ld_bw].
  *   ld_fw >= S and ld_bw >= nq: the padding columns are written as zeros, so the outputs can be the
- *        K-padded operands of odic_gemm (bf16 needs K % 64 == 0).
+ *        K-padded operands of odic_gemm (bf16 needs K % 64 == 0, ODIC_H2 K % 32 == 0); out_dtype ODIC_F32 / ODIC_BF16 /
+ *        ODIC_H2.
  *   group_meta: device int32 [ngroups+1+nq] = exclusive prefix sums of the group sizes (last = nq)
  *        followed by the group index of every query row.
  *   colsum_ws: fp32 scratch [B*ngroups*2*S].
+ *   scale_fw / scale_bw: factors applied to the fw / bw tables on output (1 = as the reference; the split-fp16 mode
+ *        writes them times a power of two so that the lo halves of these small weights stay fp16 normals, and
+ *        undoes it in the consuming product's alpha).
  * ------------------------------------------------------------------------------------------- */
 int odic_stcexp_normalize(const float* z, const int32_t* enc_len, const int32_t* group_meta,
                           int32_t ngroups, void* pos_fw, void* neg_fw, int64_t ld_fw, void* pos_bw,
                           void* neg_bw, int64_t ld_bw, float* colsum_ws, int32_t B, int32_t nq,
-                          int32_t S, float eps, int32_t out_dtype, void* stream);
+                          int32_t S, float eps, float scale_fw, float scale_bw, int32_t out_dtype, void* stream);
 
 /* out = x + sigmoid(sel_pre)·a + (1-sigmoid(sel_pre))·b     (layers.py:99-100 + the residual add of
  * EncoderLayer :120); all fp32 [M, d] with row strides. */
@@ -209,10 +227,12 @@ int odic_selector_mix(const float* x, int64_t ldx, const float* sel_pre, int64_t
  * captured graph can be replayed for every step.
  * ------------------------------------------------------------------------------------------- */
 
-/* y[n,:] = embed[tok[n]]·sqrt(d) + pos_table[pos]   (layers.py:16-17, End_ExpansionNet_v2.py:118-121) */
+/* y[n,:] = embed[tok[n]]·sqrt(d) + pos_table[pos]   (layers.py:16-17, End_ExpansionNet_v2.py:118-121).
+ * pos_rows = rows of pos_table (pos_encoder = nn.Embedding(max_seq_len, d), End_ExpansionNet_v2.py:105): *pos is device
+ * memory, so the bound is checked ON the device — a launch with *pos outside [0, pos_rows) writes nothing. */
 int odic_dec_embed(const int64_t* tokens, const float* embed, const float* pos_table,
-                   const int32_t* pos, float* y, int64_t ldy, int32_t N, int32_t d, float scale,
-                   void* stream);
+                   const int32_t* pos, float* y, int64_t ldy, int32_t N, int32_t d, int32_t pos_rows,
+                   float scale, void* stream);
 
 /* Dynamic expansion for the newest position (layers.py:152-204), with per-position caches.
  *   lin fp32 [N, >=5d] (ldlin): cond | key | class_a | class_b | selector-pre-activation of
@@ -230,7 +250,8 @@ int odic_dec_embed(const int64_t* tokens, const float* embed, const float* pos_t
  *   row_valid int32 [N]: 0 → padded row (finished beam): the block contributes 0 (masked rows of
  *        utils/masking.py:37-47), caches are still written.
  *   y_in fp32 [N,d] (ldy_in) → y fp32 [N,d] (ldy):  y = y_in + sel·A' + (1-sel)·B'  (may alias).
- *   T <= 128, E in {4, 8, 16, 32}, d a multiple of 64; one launch (one 512-thread block per sequence).
+ *   T <= 128, E in {4, 8, 16, 32}, d a multiple of 64; one launch (one 1024-thread block per sequence).
+ *   A launch with *pos outside [0, T) changes nothing (the caches hold T positions; checked on the device).
  */
 int odic_dynexp_step(const float* lin, int64_t ldlin, const float* qexp, const float* bexp,
                      float* cond_c, float* key_c, float* va_c, float* vb_c, float* wfa_c,
@@ -294,9 +315,10 @@ typedef struct odic_beam_state {
 /* Optional tail of the launch that chooses the next words: the decoder input of the next position,
  *   y[n] = embed[word_n]·scale + pos_table[pos + 1]   (EmbeddingLayer, layers.py:118-121 — what odic_dec_embed does in
  * a launch of its own), written while pos + 1 <= T - 2 (the last prefix position is never fed back);
- * embed fp32 [V, d], pos_table fp32 [>= T - 1, d], y fp32 [n_img·beams, d] (ldy). */
+ * embed fp32 [V, d], pos_table fp32 [pos_rows, d], y fp32 [n_img·beams, d] (ldy); nothing is written for a position
+ * pos + 1 >= pos_rows (device-side bound, as odic_dec_embed). */
 typedef struct odic_embed_args {
-  const float* embed; const float* pos_table; float* y; int64_t ldy; int32_t d; float scale;
+  const float* embed; const float* pos_table; float* y; int64_t ldy; int32_t d; float scale; int32_t pos_rows;
 } odic_embed_args;
 /*   Limits: beams <= 16, 2 <= T <= 128 (per-token log-probs are staged in LDS), n_img <= 32767 (the
  *   arrival counter packs {arrivals, still-growing images} into one int32): ODIC_EINVAL otherwise.

@@ -12,9 +12,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libodic_hip.so")
 
-F32, BF16, FP8, F16 = 0, 1, 2, 3
+F32, BF16, FP8, F16, H2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _ERR = {-1: "ODIC_EINVAL (bad shape / alignment / enum)", -2: "ODIC_ENULL (required pointer is NULL)",
         -3: "ODIC_EUNSUPPORTED"}
@@ -44,7 +44,7 @@ class BeamState(C.Structure):
 class EmbedArgs(C.Structure):
     """odic_embed_args: the next position's input embedding as the tail of the launch that chooses the words."""
     _fields_ = [("embed", C.c_void_p), ("pos_table", C.c_void_p), ("y", C.c_void_p), ("ldy", C.c_int64),
-                ("d", C.c_int32), ("scale", C.c_float)]
+                ("d", C.c_int32), ("scale", C.c_float), ("pos_rows", C.c_int32)]
 
 
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -55,15 +55,17 @@ _SIGNATURES = {
     "odic_gemm": (C.c_int, [C.POINTER(GemmArgs), _P]),
     "odic_layernorm": (C.c_int, [_P, _I64, _P, _P, _P, _I32, _I32, _F, _I32, _P]),
     "odic_cast_f32_to_bf16": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P]),
+    "odic_cast_f32_to_h2": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P]),
     "odic_patch_merge_layernorm": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _F, _I32, _P]),
     "odic_patch_embed": (C.c_int, [_P] * 6 + [_I32] * 6 + [_F, _P]),
     "odic_resize_bilinear_normalize": (C.c_int, [_P, _I32, _I32, _I64, _P, _P, _I32, _P, _P, _I32, _P, _P, _I32,
                                                  C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "odic_window_attention": (C.c_int, [_P, _P, _P, _P] + [_I32] * 6 + [_F, _I32, _P]),
-    "odic_stcexp_normalize": (C.c_int, [_P, _P, _P, _I32, _P, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _I32, _P]),
+    "odic_stcexp_normalize": (C.c_int, [_P, _P, _P, _I32, _P, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _F, _F, _I32,
+                                        _P]),
     "odic_selector_mix": (C.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _P]),
     "odic_copy": (C.c_int, [_P, _P, _I64, _P]),
-    "odic_dec_embed": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
+    "odic_dec_embed": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _F, _P]),
     "odic_dynexp_step": (C.c_int, [_P, _I64, _P, _P] + [_P] * 7 + [_P, _P, _P, _P, _I64, _P, _I64] + [_I32] * 4 + [_F, _P]),
     "odic_cross_attn_step": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P, _P, _P, _I64] + [_I32] * 5 + [_P]),
     "odic_logsoftmax_topk": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _P]),

@@ -49,10 +49,17 @@ class CaptioningModel(nn.Module):
         """'fp32' (default; exact-fp32 MFMA, parity mode), 'bf16' (backbone GEMMs + window attention in bf16 with
         fp32 accumulation and an fp32 residual stream; expansion-encoder products in bf16 too unless
         `encoder_precision='fp32'`) or 'fp8' (BASELINE.json configs[4]: Swin-block GEMMs qkv / fc1 / fc2 on the fp8
-        MFMA with statically calibrated scales, fp16 qkv / attention activations, everything else as 'bf16').
-        The decoder is always fp32."""
-        if precision not in ("fp32", "bf16", "fp8") or (encoder_precision or "bf16") not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32', 'bf16' or 'fp8' (encoder_precision 'fp32' or 'bf16')")
+        MFMA with statically calibrated scales, fp16 qkv / attention activations, everything else as 'bf16'), or
+        'x3' — the near-exact fast mode: every backbone / encoder contraction on split-fp16 operands (hi + lo pairs,
+        22 significand bits, three fp16 MFMAs per product with fp32 accumulation; 'bf16x3' is accepted as an alias
+        for the name the technique usually goes by), fp32 residual streams, exact-erf GELU — the mode that reproduces
+        the fp32 (= reference) captions at several times the exact-fp32 MFMA rate.  The decoder is always fp32."""
+        if precision == "bf16x3":
+            precision = "x3"
+        if encoder_precision == "bf16x3":
+            encoder_precision = "x3"
+        if precision not in ("fp32", "bf16", "fp8", "x3") or (encoder_precision or "bf16") not in ("fp32", "bf16", "x3"):
+            raise ValueError("precision must be 'fp32', 'bf16', 'fp8' or 'x3' (encoder_precision 'fp32', 'bf16' or 'x3')")
         if (precision, encoder_precision) != (self.precision, self.encoder_precision):
             self.precision, self.encoder_precision = precision, encoder_precision
             self._eng_cache = None

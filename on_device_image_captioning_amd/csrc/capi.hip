@@ -5,6 +5,7 @@
 int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream);
 int odic_gemm_f32_launch(const odic_gemm_args* a, hipStream_t stream);
 int odic_gemm_lowp_launch(const odic_gemm_args* a, hipStream_t stream);
+int odic_gemm_x3_launch(const odic_gemm_args* a, hipStream_t stream);
 
 extern "C" int odic_abi_version(void) { return ODIC_ABI_VERSION; }
 
@@ -22,6 +23,7 @@ extern "C" int odic_gemm(const odic_gemm_args* a, void* stream) {
   if (a->batch > 65535) return ODIC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (a->in_dtype == ODIC_FP8 || a->in_dtype == ODIC_F16) return odic_gemm_lowp_launch(a, s);
+  if (a->in_dtype == ODIC_H2) return odic_gemm_x3_launch(a, s);
   if (a->out_dtype != ODIC_F32 && a->out_dtype != ODIC_BF16) return ODIC_EINVAL;
   if (a->in_dtype == ODIC_BF16) return odic_gemm_bf16_launch(a, s);
   if (a->in_dtype == ODIC_F32) return odic_gemm_f32_launch(a, s);

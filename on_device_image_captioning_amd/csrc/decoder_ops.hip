@@ -46,10 +46,12 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const long long* __restr
                                                         const float* __restrict__ embed,
                                                         const float* __restrict__ pos_table,
                                                         const int* __restrict__ pos, float* __restrict__ y,
-                                                        long ldy, int N, int d, float scale) {
+                                                        long ldy, int N, int d, int pos_rows, float scale) {
   const int n = blockIdx.x;
   const long tok = tokens[n];
   const int p = *pos;
+  if (p < 0 || p >= pos_rows) return;   // *pos is device memory no host check can see: a replay past the table's last
+                                        // row (End_ExpansionNet_v2.py:105 caps the positions at max_seq_len) writes nothing
   for (int c = threadIdx.x; c < d; c += blockDim.x)
     y[n * ldy + c] = embed[tok * d + c] * scale + pos_table[(long)p * d + c];
 }
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(DYN_NT) void dynexp_step_kernel(DynParams p) {
   constexpr int NTD = DYN_NT;
   const int d = p.d, E = p.E, T = p.T, n = blockIdx.x, tid = threadIdx.x;
   const int t = *p.pos;
+  if (t < 0 || t >= T) return;         // the caches hold T positions: a step replayed past the last one changes nothing
   float* cond_t = sm;                  // [d]
   float* key_t = cond_t + d;           // [d]
   float* dk = key_t + d;               // [T]  cond_t·key_j
@@ -720,7 +723,7 @@ struct BeamParams {
   int* pos; int* done; int* ctr;
   int n_img, k, T; long long eos;
 };
-struct EmbedArgs { const float* embed; const float* pos_table; float* y; long ldy; int d; float scale; };
+struct EmbedArgs { const float* embed; const float* pos_table; float* y; long ldy; int d; float scale; int pos_rows; };
 
 struct BeamShared {
   float cv[MAX_K * MAX_K]; int ci[MAX_K * MAX_K];      // candidates: log-prob, word  [beam][rank]
@@ -832,8 +835,8 @@ __device__ __forceinline__ void beam_update(const BeamParams& p, const EmbedArgs
       }
     }
   }
-  if (e.embed && t + 2 < T) {                           // input of the next position for the k chosen words (the
-                                                        // last prefix position T-1 is never fed back)
+  if (e.embed && t + 2 < T && t + 1 < e.pos_rows) {     // input of the next position for the k chosen words (the
+                                                        // last prefix position T-1 is never fed back; never past the table)
     const float* prow = e.pos_table + (long)(t + 1) * e.d;
     for (int i = tid; i < k * e.d; i += NT) {
       const int r = i / e.d, c = i - r * e.d;
@@ -953,12 +956,12 @@ __global__ void beam_reset_kernel(long long* tok, float* lp, int* row_valid, lon
 }  // namespace
 
 extern "C" int odic_dec_embed(const int64_t* tokens, const float* embed, const float* pos_table,
-                              const int32_t* pos, float* y, int64_t ldy, int32_t N, int32_t d, float scale,
-                              void* stream) {
+                              const int32_t* pos, float* y, int64_t ldy, int32_t N, int32_t d, int32_t pos_rows,
+                              float scale, void* stream) {
   if (!tokens || !embed || !pos_table || !pos || !y) return ODIC_ENULL;
-  if (N <= 0 || d <= 0) return ODIC_EINVAL;
+  if (N <= 0 || d <= 0 || pos_rows <= 0) return ODIC_EINVAL;
   hipLaunchKernelGGL(dec_embed_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const long long*)tokens, embed,
-                     pos_table, pos, y, (long)ldy, N, d, scale);
+                     pos_table, pos, y, (long)ldy, N, d, pos_rows, scale);
   return odic_launch_status();
 }
 
@@ -1082,11 +1085,12 @@ static int beam_params(BeamParams& p, EmbedArgs& e, const odic_beam_state* st, c
   p.cumul = st->cumul; p.n_elem = st->n_elem; p.has_eos = st->has_eos; p.row_valid = st->row_valid;
   p.next_tok = (long long*)st->next_tok; p.pos = st->pos; p.done = st->done; p.ctr = st->ctr;
   p.n_img = n_img; p.k = beams; p.T = T; p.eos = eos_idx;
-  e.embed = nullptr; e.pos_table = nullptr; e.y = nullptr; e.ldy = 0; e.d = 0; e.scale = 0.f;
+  e.embed = nullptr; e.pos_table = nullptr; e.y = nullptr; e.ldy = 0; e.d = 0; e.scale = 0.f; e.pos_rows = 0;
   if (emb) {
     if (!emb->embed || !emb->pos_table || !emb->y) return ODIC_ENULL;
-    if (emb->d <= 0) return ODIC_EINVAL;
+    if (emb->d <= 0 || emb->pos_rows <= 0) return ODIC_EINVAL;
     e.embed = emb->embed; e.pos_table = emb->pos_table; e.y = emb->y; e.ldy = emb->ldy; e.d = emb->d; e.scale = emb->scale;
+    e.pos_rows = emb->pos_rows;
   }
   return 0;
 }
@@ -1142,11 +1146,12 @@ extern "C" int odic_beam_finalize_best(const odic_beam_state* st, int32_t* order
 extern "C" int odic_beam_reset(const odic_beam_state* st, const odic_embed_args* emb, int32_t n_img, int32_t beams,
                                int32_t T, int64_t sos_idx, void* stream) {
   if (!st) return ODIC_ENULL;
-  EmbedArgs e; e.embed = nullptr; e.pos_table = nullptr; e.y = nullptr; e.ldy = 0; e.d = 0; e.scale = 0.f;
+  EmbedArgs e; e.embed = nullptr; e.pos_table = nullptr; e.y = nullptr; e.ldy = 0; e.d = 0; e.scale = 0.f; e.pos_rows = 0;
   if (emb) {
     if (!emb->embed || !emb->pos_table || !emb->y) return ODIC_ENULL;
-    if (emb->d <= 0) return ODIC_EINVAL;
+    if (emb->d <= 0 || emb->pos_rows <= 0) return ODIC_EINVAL;
     e.embed = emb->embed; e.pos_table = emb->pos_table; e.y = emb->y; e.ldy = emb->ldy; e.d = emb->d; e.scale = emb->scale;
+    e.pos_rows = emb->pos_rows;
   }
   if (!st->tokens || !st->logprobs || !st->row_valid || !st->next_tok || !st->pos || !st->done || !st->ctr)
     return ODIC_ENULL;

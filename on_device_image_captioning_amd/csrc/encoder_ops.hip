@@ -19,7 +19,7 @@ template <typename OutT>
 __global__ __launch_bounds__(256) void stcexp_fw_kernel(const float* __restrict__ z,
                                                         const int* __restrict__ enc_len,
                                                         OutT* __restrict__ pos_fw, OutT* __restrict__ neg_fw,
-                                                        int B, int nq, int S, int ld, float eps) {
+                                                        int B, int nq, int S, int ld, float eps, float osc) {
   ODIC_ENCODE_PRIO();
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -37,8 +37,8 @@ __global__ __launch_bounds__(256) void stcexp_fw_kernel(const float* __restrict_
   const float ip = 1.0f / (sp + eps), in_ = 1.0f / (sn + eps);
   for (int s = lane; s < ld; s += 64) {
     const float v = (s < S && s < len) ? zr[s] : 0.f;
-    store_from_f32<OutT>(pos_fw + row * ld + s, fmaxf(v, 0.f) * ip);
-    store_from_f32<OutT>(neg_fw + row * ld + s, fmaxf(-v, 0.f) * in_);
+    store_from_f32<OutT>(pos_fw + row * ld + s, fmaxf(v, 0.f) * ip * osc);     // (osc = 1: exactly the reference value)
+    store_from_f32<OutT>(neg_fw + row * ld + s, fmaxf(-v, 0.f) * in_ * osc);
   }
 }
 
@@ -129,31 +129,40 @@ __global__ __launch_bounds__(256) void selector_mix_kernel(const float* __restri
 template <typename OutT>
 static int stcexp_launch(const float* z, const int32_t* enc_len, const int32_t* group_meta, int32_t ngroups,
                          void* pos_fw, void* neg_fw, int64_t ld_fw, void* pos_bw, void* neg_bw, int64_t ld_bw,
-                         float* colsum_ws, int32_t B, int32_t nq, int32_t S, float eps, hipStream_t s) {
+                         float* colsum_ws, int32_t B, int32_t nq, int32_t S, float eps, float scale_fw, float scale_bw,
+                         hipStream_t s) {
   const long rows = (long)B * nq;
   hipLaunchKernelGGL(stcexp_fw_kernel<OutT>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, enc_len,
-                     (OutT*)pos_fw, (OutT*)neg_fw, B, nq, S, (int)ld_fw, eps);
+                     (OutT*)pos_fw, (OutT*)neg_fw, B, nq, S, (int)ld_fw, eps, scale_fw);
   hipLaunchKernelGGL(stcexp_colsum_kernel, dim3((S + 63) / 64, ngroups, B), dim3(64, 8), 0, s, z, group_meta,
                      colsum_ws, nq, S);
   hipLaunchKernelGGL(stcexp_bw_kernel<OutT>, dim3((S + 31) / 32, (unsigned)((ld_bw + 31) / 32), B), dim3(32, 8), 0, s,
                      z, colsum_ws, group_meta + ngroups + 1, (OutT*)pos_bw, (OutT*)neg_bw, nq, S, (int)ld_bw, ngroups,
-                     eps, 1.0f / (float)ngroups);
+                     eps, scale_bw / (float)ngroups);
   return odic_launch_status();
 }
 
 extern "C" int odic_stcexp_normalize(const float* z, const int32_t* enc_len, const int32_t* group_meta,
                                      int32_t ngroups, void* pos_fw, void* neg_fw, int64_t ld_fw, void* pos_bw,
                                      void* neg_bw, int64_t ld_bw, float* colsum_ws, int32_t B, int32_t nq, int32_t S,
-                                     float eps, int32_t out_dtype, void* stream) {
+                                     float eps, float scale_fw, float scale_bw, int32_t out_dtype, void* stream) {
   if (!z || !enc_len || !group_meta || !pos_fw || !neg_fw || !pos_bw || !neg_bw || !colsum_ws) return ODIC_ENULL;
   if (B <= 0 || nq <= 0 || S <= 0 || ngroups <= 0 || B > 65535 || ld_fw < S || ld_bw < nq) return ODIC_EINVAL;
+  if (!(scale_fw > 0.f) || !(scale_bw > 0.f)) return ODIC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (out_dtype == ODIC_F32)
     return stcexp_launch<float>(z, enc_len, group_meta, ngroups, pos_fw, neg_fw, ld_fw, pos_bw, neg_bw, ld_bw,
-                                colsum_ws, B, nq, S, eps, s);
+                                colsum_ws, B, nq, S, eps, scale_fw, scale_bw, s);
   if (out_dtype == ODIC_BF16)
     return stcexp_launch<bf16_raw>(z, enc_len, group_meta, ngroups, pos_fw, neg_fw, ld_fw, pos_bw, neg_bw, ld_bw,
-                                   colsum_ws, B, nq, S, eps, s);
+                                   colsum_ws, B, nq, S, eps, scale_fw, scale_bw, s);
+  if (out_dtype == ODIC_H2) {             // split-fp16 operands of the x3 GEMM: whole [8 hi | 8 lo] groups per row
+    if ((ld_fw & 7) || (ld_bw & 7) || ((uintptr_t)pos_fw & 31) || ((uintptr_t)neg_fw & 31) || ((uintptr_t)pos_bw & 31) ||
+        ((uintptr_t)neg_bw & 31))
+      return ODIC_EINVAL;
+    return stcexp_launch<h2_t>(z, enc_len, group_meta, ngroups, pos_fw, neg_fw, ld_fw, pos_bw, neg_bw, ld_bw,
+                               colsum_ws, B, nq, S, eps, scale_fw, scale_bw, s);
+  }
   return ODIC_EINVAL;
 }
 

@@ -339,8 +339,13 @@ int odic_gemm_f32_launch(const odic_gemm_args* a, hipStream_t stream) {
   if (want_ln && !(skinny_ok && a->bias_axis == 0)) return ODIC_EUNSUPPORTED;
   if (skinny_ok && (a->N >= 64 || want_ln) && !(a->tile_cfg == 3 && !want_ln)) {     // (3: the 64x64 tile kernel)
     const int mt = (a->M + 15) / 16, ct = (a->N + 15) / 16;
+    // The decomposition fixes the K-summation order (up to 16 K-slices in shape 1, up to 8 in shape 2), so it is
+    // chosen from the product's (N, K) alone — never from M: the same logical product (a decoder weight) must sum in
+    // the same order whether 48 rows (one batch) or 96 rows (a decode group of two) go through it, or a grouped
+    // search would differ from the per-batch search at near-ties.  Wide products (the vocabulary: 625 column tiles)
+    // take the three-row-tiles-per-wave shape, everything else one row tile per block.
     int shape = a->tile_cfg;
-    if (shape < 0 || shape > 2) shape = (long)ct * mt * a->batch <= 768 ? 1 : 2;
+    if (shape < 0 || shape > 2) shape = ct <= 256 ? 1 : 2;
     if (shape == 1) {
       launch_skinny<1, 4, ODIC_SKINNY_MAXW>(p, a->out_dtype, a->batch, stream, mt, 16);
     } else if (shape == 2) {

@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       const float o2 = (v[t].z - mean) * rstd * g.z + bb.z;
       const float o3 = (v[t].w - mean) * rstd * g.w + bb.w;
       OutT* dst = out + (long)row * C + 4 * idx;
-      if constexpr (sizeof(OutT) == 4) {
+      if constexpr (__is_same(OutT, h2_t)) {     // split-fp16 operand of the x3 GEMM: 8 bytes into each plane
+        h2_store4(out + (long)row * C, 4 * idx, o0, o1, o2, o3);
+      } else if constexpr (sizeof(OutT) == 4) {
         *(float4*)dst = make_float4(o0, o1, o2, o3);
       } else if constexpr (sizeof(OutT) == 2) {
         ushort4 pk;
@@ -216,16 +218,21 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, long ldx,
-                                                        bf16_raw* __restrict__ out, long ldo, int M, int C4) {
+template <typename OutT>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, long ldx,
+                                                   OutT* __restrict__ out, long ldo, int M, int C4) {
   ODIC_ENCODE_PRIO();
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)M * C4) return;
   const int r = i / C4, c = (i - (long)r * C4) * 4;
   const float4 v = *(const float4*)(x + r * ldx + c);
-  ushort4 pk;
-  pk.x = f32_to_bf16(v.x); pk.y = f32_to_bf16(v.y); pk.z = f32_to_bf16(v.z); pk.w = f32_to_bf16(v.w);
-  *(ushort4*)(out + r * ldo + c) = pk;
+  if constexpr (__is_same(OutT, h2_t)) {
+    h2_store4(out + r * ldo, c, v.x, v.y, v.z, v.w);
+  } else {
+    ushort4 pk;
+    pk.x = f32_to_bf16(v.x); pk.y = f32_to_bf16(v.y); pk.z = f32_to_bf16(v.z); pk.w = f32_to_bf16(v.w);
+    *(ushort4*)(out + r * ldo + c) = pk;
+  }
 }
 
 // plain copy of 16-byte units, grid-stride (the K/V hand-off of the pipeline: the consumer kernels then read what a
@@ -252,8 +259,19 @@ extern "C" int odic_cast_f32_to_bf16(const float* x, int64_t ldx, void* out, int
   if (M <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldo & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 7))
     return ODIC_EINVAL;
   const long n = (long)M * (C / 4);
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+  hipLaunchKernelGGL(cast_kernel<bf16_raw>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
                      (long)ldx, (bf16_raw*)out, (long)ldo, M, C / 4);
+  return odic_launch_status();
+}
+
+extern "C" int odic_cast_f32_to_h2(const float* x, int64_t ldx, void* out, int64_t ldo, int32_t M, int32_t C,
+                                   void* stream) {
+  if (!x || !out) return ODIC_ENULL;
+  if (M <= 0 || C <= 0 || (C & 7) || (ldx & 3) || (ldo & 7) || ((uintptr_t)x & 15) || ((uintptr_t)out & 31))
+    return ODIC_EINVAL;
+  const long n = (long)M * (C / 4);
+  hipLaunchKernelGGL(cast_kernel<h2_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)ldx, (h2_t*)out, (long)ldo, M, C / 4);
   return odic_launch_status();
 }
 
@@ -266,6 +284,10 @@ extern "C" int odic_layernorm(const float* x, int64_t ldx, const float* gamma, c
   if (out_dtype == ODIC_F32) return launch_ln<false, float>(x, ldx, gamma, beta, out, M, C, eps, 0, 0, s);
   if (out_dtype == ODIC_BF16) return launch_ln<false, bf16_raw>(x, ldx, gamma, beta, out, M, C, eps, 0, 0, s);
   if (out_dtype == ODIC_FP8) return launch_ln<false, unsigned char>(x, ldx, gamma, beta, out, M, C, eps, 0, 0, s);
+  if (out_dtype == ODIC_H2) {
+    if ((C & 7) || ((uintptr_t)out & 31)) return ODIC_EINVAL;
+    return launch_ln<false, h2_t>(x, ldx, gamma, beta, out, M, C, eps, 0, 0, s);
+  }
   return ODIC_EINVAL;
 }
 
@@ -278,6 +300,10 @@ extern "C" int odic_patch_merge_layernorm(const float* x, const float* gamma, co
   const int M = B * (res / 2) * (res / 2);
   if (out_dtype == ODIC_F32) return launch_ln<true, float>(x, 0, gamma, beta, out, M, 4 * C, eps, res, C, s);
   if (out_dtype == ODIC_BF16) return launch_ln<true, bf16_raw>(x, 0, gamma, beta, out, M, 4 * C, eps, res, C, s);
+  if (out_dtype == ODIC_H2) {
+    if ((C & 1) || ((uintptr_t)out & 31)) return ODIC_EINVAL;
+    return launch_ln<true, h2_t>(x, 0, gamma, beta, out, M, 4 * C, eps, res, C, s);
+  }
   return ODIC_EINVAL;
 }
 

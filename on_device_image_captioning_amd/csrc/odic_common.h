@@ -39,6 +39,57 @@ __device__ __forceinline__ unsigned f32x4_to_fp8(float a, float b, float c, floa
   return (unsigned)v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-fp16 ("h2", dtype code ODIC_H2) — the operand format of the near-exact fast mode (`precision='x3'`).
+// A value is carried as hi + lo with hi = fp16(x), lo = fp16(x − hi): 22 significand bits, and a product
+// a·w ≈ ah·wh + ah·wl + al·wh runs as THREE fp16 MFMAs (fp32 accumulate) instead of one 16x-slower fp32 MFMA.
+// Memory layout: 4 bytes per element like fp32 — leading dimensions, strides and buffer sizes are those of an fp32
+// tensor — but in groups of 8 consecutive K-elements: [8 x hi fp16 | 8 x lo fp16] (32 bytes), so that a lane's
+// 16-byte MFMA fragment (8 consecutive k of one plane) is ONE aligned 16-byte chunk and a producer that owns 8
+// adjacent columns stores 32 contiguous bytes.  All-zero bytes are the value 0.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+struct h2_t { unsigned v; };                    // tag type: one h2 element slot (4 bytes)
+
+__device__ __forceinline__ void h2_split(float x, f16_t& hi, f16_t& lo) {
+  x = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);       // saturate instead of producing inf (inf − inf = NaN)
+  hi = (f16_t)x;
+  lo = (f16_t)(x - (float)hi);
+}
+// eight consecutive elements (col % 8 == 0) → the group's 32 bytes at element address `dst`
+__device__ __forceinline__ void h2_store8(h2_t* dst, const float* v) {
+  f16x8_t hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { f16_t h, l; h2_split(v[e], h, l); hi[e] = h; lo[e] = l; }
+  ((f16x8_t*)dst)[0] = hi;
+  ((f16x8_t*)dst)[1] = lo;
+}
+// four consecutive elements starting at column c (c % 4 == 0) of the row that starts at `row`: 8 bytes into each plane
+__device__ __forceinline__ void h2_store4(h2_t* row, int c, float a, float b, float cc, float d) {
+  f16x4_t hi, lo;
+  f16_t h, l;
+  h2_split(a, h, l); hi[0] = h; lo[0] = l;
+  h2_split(b, h, l); hi[1] = h; lo[1] = l;
+  h2_split(cc, h, l); hi[2] = h; lo[2] = l;
+  h2_split(d, h, l); hi[3] = h; lo[3] = l;
+  char* g = (char*)row + (long)(c >> 3) * 32 + (c & 4) * 2;
+  *(f16x4_t*)g = hi;
+  *(f16x4_t*)(g + 16) = lo;
+}
+__device__ __forceinline__ void h2_store1(h2_t* row, int c, float x) {
+  f16_t h, l;
+  h2_split(x, h, l);
+  char* g = (char*)row + (long)(c >> 3) * 32 + (c & 7) * 2;
+  *(f16_t*)g = h;
+  *(f16_t*)(g + 16) = l;
+}
+__device__ __forceinline__ float h2_load1(const h2_t* row, int c) {
+  const char* g = (const char*)row + (long)(c >> 3) * 32 + (c & 7) * 2;
+  return (float)*(const f16_t*)g + (float)*(const f16_t*)(g + 16);
+}
+
 template <typename T> __device__ __forceinline__ float load_as_f32(const T* p);
 template <> __device__ __forceinline__ float load_as_f32<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_as_f32<bf16_raw>(const bf16_raw* p) { return bf16_to_f32(*p); }
@@ -46,6 +97,16 @@ template <> __device__ __forceinline__ float load_as_f32<bf16_raw>(const bf16_ra
 template <typename T> __device__ __forceinline__ void store_from_f32(T* p, float v);
 template <> __device__ __forceinline__ void store_from_f32<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_from_f32<bf16_raw>(bf16_raw* p, float v) { *p = f32_to_bf16(v); }
+// one h2 element by its slot address (rows start on 32-byte boundaries: the group and the position inside it follow
+// from the address alone)
+template <> __device__ __forceinline__ void store_from_f32<h2_t>(h2_t* p, float v) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  char* g = reinterpret_cast<char*>(a & ~(uintptr_t)31) + ((a >> 2) & 7) * 2;
+  f16_t h, l;
+  h2_split(v, h, l);
+  *(f16_t*)g = h;
+  *(f16_t*)(g + 16) = l;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -514,6 +514,199 @@ __global__ __launch_bounds__(192, 4) void window_attention_bf16_v3_kernel(WinPar
   }
 }
 
+
+// =================================================================================================
+// Split-fp16 ("h2") flavour of the v3 kernel — the attention core of the near-exact fast mode (`precision='x3'`).
+// q, k, v arrive as hi + lo fp16 pairs (odic_common.h; a head's 32 channels are 128 bytes: [8 hi | 8 lo] x 4) and
+// both contractions run as three fp16 MFMAs each:  S = Kh·Qh + Kh·Ql + Kl·Qh,  O = Vh·Ph + Vh·Pl + Vl·Ph  with
+// P = exp2(...)·2^12 split into hi + lo as it is produced (the 2^12 keeps the lo halves of the small probabilities
+// out of the fp16 subnormals; it cancels in the row normalisation).  Everything between the MFMAs — bias as the
+// accumulator init, base-2 softmax on the raw fp32 accumulators, mask — is the v3 code.
+//   K image  [144][128 B]: per row the four hi fragments then the four lo fragments, slots XOR-swizzled with row & 7
+//            (the planar order and the swizzle are applied through the per-lane LDS-DMA source address);
+//   V images [160][64 B] x 2 (hi, lo), consumed through ds_read_b64_tr_b16 exactly like the 16-bit kernel's V.
+// 48 KiB of LDS → three blocks per CU.
+// =================================================================================================
+__global__ __launch_bounds__(192, 3) void window_attention_h2_kernel(WinParams p) {
+  __shared__ __attribute__((aligned(16))) char Kx[MAXN * 128];          // 18432 B
+  __shared__ __attribute__((aligned(16))) bf16_raw Vh[MAXN + 16][HD];   // 10240 B (rows 144..159 zero)
+  __shared__ __attribute__((aligned(16))) bf16_raw Vl[MAXN + 16][HD];   // 10240 B
+  __shared__ __attribute__((aligned(16))) float Bs[4 * BS_COPY];        // 9216 B
+  __shared__ int rows[MAXN];
+  __shared__ __attribute__((aligned(4))) unsigned char rids[MAXN];
+
+  ODIC_ENCODE_PRIO();
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int head = idx % p.heads;
+  const int win = (idx / p.heads) * 8 + xcd;
+  const int wpi = p.nwin_side * p.nwin_side;
+  if (win >= p.B * wpi) return;
+  const int b = win / wpi, wrem = win - b * wpi;
+  const int wy = wrem / p.nwin_side, wx = wrem - wy * p.nwin_side;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const char* qkv = (const char*)p.qkv;
+  const long ldb = 12L * p.C;                                           // bytes per token row of [*, 3C] h2
+  const long kbyte = 4L * p.C, vbyte = 8L * p.C;                        // byte offsets of the k / v column blocks
+  const bool masked = p.shift > 0 && (wy == p.nwin_side - 1 || wx == p.nwin_side - 1);
+
+  {
+    const float* bsrc = p.bias_shifted + (long)head * 4 * BS_COPY + lane * 4;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int blk = wave * 3 + i;
+      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc + blk * 256), (lptr_t)((char*)&Bs[0] + blk * 1024), 16, 0, 0);
+    }
+  }
+  if (tid < MAXN) {
+    long r; int rid;
+    slot_to_token(p, b, wy, wx, tid, r, rid);
+    rows[tid] = (int)r; rids[tid] = (unsigned char)rid;
+  }
+  if (tid < 128) { ((unsigned long long*)&Vh[MAXN][0])[tid] = 0ull; ((unsigned long long*)&Vl[MAXN][0])[tid] = 0ull; }
+  __syncthreads();
+
+  // ---- LDS-DMA gather.  K: instruction j covers window slots 8j .. 8j+7 (8 rows x 128 B); V: slots 16i .. 16i+15
+  //      of one plane (16 rows x 64 B).  Six K and six V instructions per wave.
+  {
+    const int r8 = lane >> 3, pos = lane & 7;
+    const int img = pos ^ r8;                                            // image chunk held by this LDS slot
+    const int mc = img < 4 ? 2 * img : 2 * (img - 4) + 1;                // its 16-byte chunk in memory
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int j = wave * 6 + i;                                        // 0..17
+      const char* src = qkv + (long)rows[j * 8 + r8] * ldb + kbyte + head * 128 + mc * 16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Kx + j * 1024), 16, 0, 0);
+    }
+    const int r16 = lane >> 2, ch = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int blk = wave * 3 + i;                                      // 0..8
+      const char* src = qkv + (long)rows[blk * 16 + r16] * ldb + vbyte + head * 128 + ch * 32;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)((char*)&Vh[0][0] + blk * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + 16), (lptr_t)((char*)&Vl[0][0] + blk * 1024), 16, 0, 0);
+    }
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  const float scale2 = p.scale * 1.4426950408889634f;
+  const float mask_acc = 100.0f / p.scale;
+  const int voff = ((4 * fq + (fr >> 2)) * HD + 4 * (fr & 3)) * 2;
+  int koffs[9];
+#pragma unroll
+  for (int kt = 0; kt < 9; ++kt) {
+    const int key0 = kt * 16 + fq * 4;
+    const int jy = key0 / 12, jx0 = key0 - jy * 12;
+    koffs[kt] = (jx0 - jy * 24) * 4;
+  }
+  auto bias_base = [&](int qn) -> int {
+    const int iy = qn / 12, ix = qn - iy * 12;
+    const int s = (11 - ix) & 3;
+    return (s * BS_COPY + (iy + 11) * 24 + 11 - ix - s) * 4;
+  };
+
+  // first tile's Q fragments (B operand of Sᵀ = K·Qᵀ: Q[query = fr][d = 8·fq ..], hi chunk then lo chunk)
+  const char* qp = qkv + (long)rows[wave * 48 + fr] * ldb + head * 128 + fq * 32;
+  f16x8_t qh = *(const f16x8_t*)qp, ql = *(const f16x8_t*)(qp + 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+#pragma unroll
+  for (int qt = 0; qt < 3; ++qt) {
+    const int qn = (wave * 3 + qt) * 16 + fr;
+    const int orow = rows[qn];
+    int koh = fr * 128 + ((fq ^ (fr & 7)) << 4), vo = voff, bb = bias_base(qn);
+    asm volatile("" : "+v"(koh), "+v"(vo), "+v"(bb));
+    const char* kbase = Kx + koh;                                        // hi fragment; lo = slot ^ 4 → byte ^ 64
+    const char* bbase = (const char*)&Bs[0] + bb;
+    f32x4_t sc[9];
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) sc[kt] = *(const f32x4_t*)(bbase + koffs[kt]);
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+      const f16x8_t kh = *(const f16x8_t*)(kbase + kt * 16 * 128);
+      const f16x8_t kl = *(const f16x8_t*)(Kx + ((koh ^ 64) + kt * 16 * 128));
+      sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, sc[kt], 0, 0, 0);
+      sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, sc[kt], 0, 0, 0);
+      sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, sc[kt], 0, 0, 0);
+    }
+    if (masked) {
+      const unsigned my = rids[qn];
+#pragma unroll
+      for (int kt = 0; kt < 9; ++kt) {
+        const unsigned kr = *(const unsigned*)&rids[kt * 16 + fq * 4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (((kr >> (8 * j)) & 0xff) != my) sc[kt][j] -= mask_acc;
+      }
+    }
+    float m = max3f(sc[0][0], sc[0][1], sc[0][2]);
+    m = max3f(m, sc[0][3], sc[1][0]);
+    m = max3f(m, sc[1][1], sc[1][2]);
+#pragma unroll
+    for (int kt = 2; kt < 9; kt += 2) {
+      m = max3f(m, sc[kt - 1][3], sc[kt][0]);
+      m = max3f(m, sc[kt][1], sc[kt][2]);
+      if (kt + 1 < 9) {
+        m = max3f(m, sc[kt][3], sc[kt + 1][0]);
+        m = max3f(m, sc[kt + 1][1], sc[kt + 1][2]);
+      } else {
+        m = fmaxf(m, sc[kt][3]);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float c2 = 12.0f - m * scale2;                                 // P carries a factor 2^12
+    float lsum = 0.f;
+    f16x4_t ph[9], pl[9];
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][j], scale2, c2));
+        lsum += e;
+        const f16_t h = (f16_t)e;
+        ph[kt][j] = h;
+        pl[kt][j] = (f16_t)(e - (float)h);
+      }
+    }
+    if (qt < 2) {                                                        // next tile's Q under the P·V work below
+      const char* qn_p = qkv + (long)rows[qn + 16] * ldb + head * 128 + fq * 32;
+      qh = *(const f16x8_t*)qn_p; ql = *(const f16x8_t*)(qn_p + 16);
+    }
+    float l = lsum;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv_l = 1.0f / l;
+
+    f32x4_t oacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    const f16x4_t z4 = {(f16_t)0.f, (f16_t)0.f, (f16_t)0.f, (f16_t)0.f};
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+      const f16x4_t h0 = ph[2 * s5], l0 = pl[2 * s5];
+      const f16x4_t h1 = s5 < 4 ? ph[2 * s5 + (s5 < 4)] : z4, l1 = s5 < 4 ? pl[2 * s5 + (s5 < 4)] : z4;
+      const f16x8_t pfh = f16x8_t{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      const f16x8_t pfl = f16x8_t{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int off = vo + (32 * s5) * HD * 2 + nt * 32;
+        const v4s_t ah0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)((char*)&Vh[0][0] + off));
+        const v4s_t ah1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)((char*)&Vh[0][0] + off + 16 * HD * 2));
+        const v4s_t al0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)((char*)&Vl[0][0] + off));
+        const v4s_t al1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)((char*)&Vl[0][0] + off + 16 * HD * 2));
+        const bf16x8_t vh8 = bf16x8_t{ah0[0], ah0[1], ah0[2], ah0[3], ah1[0], ah1[1], ah1[2], ah1[3]};
+        const bf16x8_t vl8 = bf16x8_t{al0[0], al0[1], al0[2], al0[3], al1[0], al1[1], al1[2], al1[3]};
+        const f16x8_t vh = __builtin_bit_cast(f16x8_t, vh8), vl = __builtin_bit_cast(f16x8_t, vl8);
+        oacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, pfh, oacc[nt], 0, 0, 0);
+        oacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pfl, oacc[nt], 0, 0, 0);
+        oacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pfh, oacc[nt], 0, 0, 0);
+      }
+    }
+    h2_t* drow = (h2_t*)p.out + (long)orow * p.C + head * HD;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      h2_store4(drow, nt * 16 + fq * 4, oacc[nt][0] * inv_l, oacc[nt][1] * inv_l, oacc[nt][2] * inv_l, oacc[nt][3] * inv_l);
+  }
+}
+
 }  // namespace
 
 extern "C" int odic_window_attention(const void* qkv, const float* bias_table, const float* bias_shifted_prescaled,
@@ -546,6 +739,12 @@ extern "C" int odic_window_attention(const void* qkv, const float* bias_table, c
       return ODIC_EUNSUPPORTED;                  // fp16 activations: packed-bias MFMA kernel only
     const int nwin = B * p.nwin_side * p.nwin_side;
     hipLaunchKernelGGL(window_attention_bf16_v3_kernel<true>, dim3(((nwin + 7) / 8) * 8 * heads), block, 0, s, p);
+  } else if (dtype == ODIC_H2) {
+    if (ws != 12 || !bias_shifted_prescaled || (long)B * res * res >= 2147483647L || (((uintptr_t)bias_shifted_prescaled) & 15) ||
+        ((uintptr_t)qkv & 31) || ((uintptr_t)out & 31))
+      return ODIC_EUNSUPPORTED;                  // split-fp16 activations: packed-bias MFMA kernel only
+    const int nwin = B * p.nwin_side * p.nwin_side;
+    hipLaunchKernelGGL(window_attention_h2_kernel, dim3(((nwin + 7) / 8) * 8 * heads), block, 0, s, p);
   } else {
     return ODIC_EINVAL;
   }

@@ -29,7 +29,19 @@ SD = Dict[str, torch.Tensor]
 # precision → dtype of the backbone's bf16-class activations / weights.  "fp8" (BASELINE.json configs[4]) keeps that
 # at bf16 for the patch-merge reductions and the backbone output, and runs the Swin blocks with fp8 GEMM operands
 # (qkv, fc1, fc2: 11/12 of the block FLOPs) and fp16 qkv / attention activations (proj on the fp16 MFMA).
-_CDT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp8": torch.bfloat16}
+# "x3" (the near-exact fast mode): activations and weights travel as split-fp16 pairs (ops.H2_DTYPE: hi + lo, 22
+# significand bits, 4 bytes per element) and every contraction of the backbone and of the expansion encoder is three
+# fp16 MFMAs (csrc/gemm_x3.hip, window_attention_h2_kernel); residual streams, normalisations and the decoder are fp32.
+_CDT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp8": torch.bfloat16, "x3": ops.H2_DTYPE}
+
+
+def pack_operand(t: torch.Tensor, cdt) -> Tuple[torch.Tensor, float]:
+    """fp32 weight [N, K] → (GEMM operand in the engine's dtype, alpha that undoes its pack-time scale).  Split-fp16
+    operands are scaled by a power of two so that the lo halves are fp16 normals (exact to undo)."""
+    if cdt == ops.H2_DTYPE:
+        sc = ops.pow2_scale_for_h2(t)
+        return ops.h2_from_f32(t * sc), 1.0 / sc
+    return t.to(cdt).contiguous(), 1.0
 
 
 def _dev(t: torch.Tensor, device, dtype=None) -> torch.Tensor:
@@ -49,10 +61,10 @@ class SwinEngine:
         self.g, self.device, self.precision = g, device, precision
         self.cdt = _CDT[precision]
         fp8 = precision == "fp8"
-        fast_attn = precision in ("bf16", "fp8")
+        fast_attn = precision in ("bf16", "fp8", "x3")
         P = "swin_transf"
         f32 = lambda k: _dev(sd[k], device, torch.float32)          # noqa: E731
-        cw = lambda k: _dev(sd[k], device, torch.float32).to(self.cdt).contiguous()   # noqa: E731
+        cw = lambda k: pack_operand(_dev(sd[k], device, torch.float32), self.cdt)      # noqa: E731  (operand, alpha)
         self.pe_w = _dev(sd[f"{P}.patch_embed.proj.weight"].reshape(g.swin_embed_dim, -1), device, torch.float32)
         self.pe_b = f32(f"{P}.patch_embed.proj.bias")
         self.pe_g, self.pe_beta = f32(f"{P}.patch_embed.norm.weight"), f32(f"{P}.patch_embed.norm.bias")
@@ -61,22 +73,25 @@ class SwinEngine:
             blocks = []
             for b in range(depth):
                 p = f"{P}.layers.{s}.blocks.{b}"
+                (qkv_w, qkv_a), (proj_w, proj_a) = cw(p + ".attn.qkv.weight"), cw(p + ".attn.proj.weight")
+                (fc1_w, fc1_a), (fc2_w, fc2_a) = cw(p + ".mlp.fc1.weight"), cw(p + ".mlp.fc2.weight")
                 blocks.append(dict(
                     n1w=f32(p + ".norm1.weight"), n1b=f32(p + ".norm1.bias"),
-                    qkv_w=cw(p + ".attn.qkv.weight"), qkv_b=f32(p + ".attn.qkv.bias"),
+                    qkv_w=qkv_w, qkv_a=qkv_a, qkv_b=f32(p + ".attn.qkv.bias"),
                     table=f32(p + ".attn.relative_position_bias_table"),
                     dense=(ops.shifted_bias_prescaled(f32(p + ".attn.relative_position_bias_table"), g.stage_window(s),
                                                       (g.stage_dim(s) // g.swin_num_heads[s]) ** -0.5)
                            if fast_attn and g.stage_window(s) == 12 else None),
-                    proj_w=cw(p + ".attn.proj.weight"), proj_b=f32(p + ".attn.proj.bias"),
+                    proj_w=proj_w, proj_a=proj_a, proj_b=f32(p + ".attn.proj.bias"),
                     n2w=f32(p + ".norm2.weight"), n2b=f32(p + ".norm2.bias"),
-                    fc1_w=cw(p + ".mlp.fc1.weight"), fc1_b=f32(p + ".mlp.fc1.bias"),
-                    fc2_w=cw(p + ".mlp.fc2.weight"), fc2_b=f32(p + ".mlp.fc2.bias"),
+                    fc1_w=fc1_w, fc1_a=fc1_a, fc1_b=f32(p + ".mlp.fc1.bias"),
+                    fc2_w=fc2_w, fc2_a=fc2_a, fc2_b=f32(p + ".mlp.fc2.bias"),
                     shift=g.stage_shift(s, b)))
             down = None
             if s < len(g.swin_depths) - 1:
                 p = f"{P}.layers.{s}.downsample"
-                down = dict(nw=f32(p + ".norm.weight"), nb=f32(p + ".norm.bias"), red_w=cw(p + ".reduction.weight"))
+                red_w, red_a = cw(p + ".reduction.weight")
+                down = dict(nw=f32(p + ".norm.weight"), nb=f32(p + ".norm.bias"), red_w=red_w, red_a=red_a)
             self.stages.append((blocks, down))
         self.fn_w, self.fn_b = f32(f"{P}.norm.weight"), f32(f"{P}.norm.bias")
         # Optional (ODIC_FOLD_BACKBONE_LN=1, bf16 mode): norm2 and the norm1 of every block but a stage's first folded
@@ -182,21 +197,21 @@ class SwinEngine:
                     xn = ops.layernorm(x, w["n1w"], w["n1b"], out_dtype=cdt)
                     if _amax is not None:
                         _amax[(s, bi, "ln1")] = float(xn.float().abs().max())
-                    qkv = ops.gemm(xn, w["qkv_w"], w["qkv_b"])
+                    qkv = ops.gemm(xn, w["qkv_w"], w["qkv_b"], alpha=w["qkv_a"])
                     att = ops.window_attention(qkv, w["table"], B, res, C_, heads, ws, w["shift"],
                                                bias_shifted_prescaled=w["dense"])
-                    ops.gemm(att, w["proj_w"], w["proj_b"], residual=x, out=x)
+                    ops.gemm(att, w["proj_w"], w["proj_b"], residual=x, out=x, alpha=w["proj_a"])
                     xn = ops.layernorm(x, w["n2w"], w["n2b"], out_dtype=cdt)
-                    h = ops.gemm(xn, w["fc1_w"], w["fc1_b"], act=ops.ACT_GELU)
+                    h = ops.gemm(xn, w["fc1_w"], w["fc1_b"], act=ops.ACT_GELU, alpha=w["fc1_a"])
                     if _amax is not None:
                         _amax[(s, bi, "ln2")] = float(xn.float().abs().max())
                         _amax[(s, bi, "hid")] = float(h.float().abs().max())
-                    ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x)
+                    ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x, alpha=w["fc2_a"])
                 if taps is not None:
                     taps[f"s{s}b{bi}"] = x.view(B, res * res, C_).clone()
             if down is not None:
                 xm = ops.patch_merge_layernorm(x, down["nw"], down["nb"], B, res, C_, out_dtype=cdt)
-                x = ops.gemm(xm.view(-1, 4 * C_), down["red_w"], out_dtype=torch.float32)
+                x = ops.gemm(xm.view(-1, 4 * C_), down["red_w"], out_dtype=torch.float32, alpha=down["red_a"])
                 if taps is not None:
                     taps[f"merge{s}"] = x.view(B, (res // 2) ** 2, 2 * C_).clone()
         res = g.stage_res(len(g.swin_depths) - 1)
@@ -251,24 +266,30 @@ class CaptionerEngine:
         d = g.d_model
         f32 = lambda k: _dev(sd[k], device, torch.float32)          # noqa: E731
         cat = lambda ks: torch.cat([f32(k) for k in ks], 0).contiguous()   # noqa: E731
-        cw = lambda t: t.to(self.cdt).contiguous()                  # noqa: E731  (encoder GEMM operand dtype)
-        self.in_w, self.in_b = cw(f32("input_linear.weight")), f32("input_linear.bias")
+        cw = lambda t: pack_operand(t, self.cdt)                    # noqa: E731  (encoder GEMM operand, alpha)
+        (self.in_w, self.in_a), self.in_b = cw(f32("input_linear.weight")), f32("input_linear.bias")
         self.enc = []
         for i in range(g.N_enc):
             p = f"encoders.{i}"
             s = p + ".stc_exp"
+            q, q_a = cw(f32(s + ".query_exp_vectors.weight"))
+            key_w, key_a = cw(f32(s + ".key_embed.weight"))
+            sel_w, sel_a = cw(f32(s + ".selector_embed.weight"))
+            ab_w, ab_a = cw(cat([s + ".class_a_embed.weight", s + ".class_b_embed.weight"]))  # [2d, d]
+            f1w, f1a = cw(f32(p + ".ff.linear_1.weight"))
+            f2w, f2a = cw(f32(p + ".ff.linear_2.weight"))
             self.enc.append(dict(
                 n1w=f32(p + ".norm_1.weight"), n1b=f32(p + ".norm_1.bias"),
                 n2w=f32(p + ".norm_2.weight"), n2b=f32(p + ".norm_2.bias"),
-                q=cw(f32(s + ".query_exp_vectors.weight")),
+                q=q, q_a=q_a,
                 bvT=f32(s + ".bias_exp_vectors.weight").t().contiguous(),              # [d, nq] fp32
-                key_w=cw(f32(s + ".key_embed.weight")), key_b=f32(s + ".key_embed.bias"),
-                sel_w=cw(f32(s + ".selector_embed.weight")), sel_b=f32(s + ".selector_embed.bias"),
-                ab_w=cw(cat([s + ".class_a_embed.weight", s + ".class_b_embed.weight"])),  # [2d, d]
+                key_w=key_w, key_a=key_a, key_b=f32(s + ".key_embed.bias"),
+                sel_w=sel_w, sel_a=sel_a, sel_b=f32(s + ".selector_embed.bias"),
+                ab_w=ab_w, ab_a=ab_a,
                 ab_b=cat([s + ".class_a_embed.bias", s + ".class_b_embed.bias"]),
-                f1w=cw(f32(p + ".ff.linear_1.weight")), f1b=f32(p + ".ff.linear_1.bias"),
-                f2w=cw(f32(p + ".ff.linear_2.weight")), f2b=f32(p + ".ff.linear_2.bias")))
-        self.er_w, self.er_b = cw(f32("enc_reduce_group.weight")), f32("enc_reduce_group.bias")
+                f1w=f1w, f1a=f1a, f1b=f32(p + ".ff.linear_1.bias"),
+                f2w=f2w, f2a=f2a, f2b=f32(p + ".ff.linear_2.bias")))
+        (self.er_w, self.er_a), self.er_b = cw(f32("enc_reduce_group.weight")), f32("enc_reduce_group.bias")
         self.ern_w, self.ern_b = f32("enc_reduce_norm.weight"), f32("enc_reduce_norm.bias")
         self.group_meta = ops.stcexp_group_meta(g.num_exp_enc_list, device)
         self.dec = []
@@ -294,7 +315,7 @@ class CaptionerEngine:
             kvw += [p + ".mha.Wk.weight", p + ".mha.Wv.weight"]
             kvb += [p + ".mha.Wk.bias", p + ".mha.Wv.bias"]
         self.kv_w32, self.kv_b = cat(kvw), cat(kvb)                 # [2·N_dec·d, d]
-        self.kv_w = cw(self.kv_w32)
+        self.kv_w, self.kv_a = cw(self.kv_w32)
         self.dr_w, self.dr_b = f32("dec_reduce_group.weight"), f32("dec_reduce_group.bias")
         self.drn_w, self.drn_b = f32("dec_reduce_norm.weight"), f32("dec_reduce_norm.bias")
         self.voc_w, self.voc_b = f32("vocab_linear.weight"), f32("vocab_linear.bias")
@@ -308,6 +329,8 @@ class CaptionerEngine:
             return x
         if self.cdt == torch.bfloat16 and x.dtype == torch.float32:
             return ops.cast_bf16(x, M=M, C_=C_, ldx=ldx)
+        if self.cdt == ops.H2_DTYPE and x.dtype == torch.float32:
+            return ops.cast_h2(x, M=M, C_=C_, ldx=ldx)
         raise RuntimeError(f"cannot feed {x.dtype} to a {self.cdt} encoder")
 
     def encode(self, feats: torch.Tensor, enc_len: torch.Tensor, want_bf16_mem: bool = False):
@@ -316,14 +339,19 @@ class CaptionerEngine:
         g, dv, cdt = self.g, self.device, self.cdt
         B, S, F = feats.shape
         d, L, nq, M = g.d_model, g.N_enc, sum(g.num_exp_enc_list), B * S
-        pad = 64 if cdt == torch.bfloat16 else 1                   # the bf16 GEMM needs K % 64 == 0
+        x3 = cdt == ops.H2_DTYPE
+        pad = 64 if cdt == torch.bfloat16 else (32 if x3 else 1)   # the bf16 / split-fp16 GEMMs need K % 64 / 32 == 0
+        # split fp16: the normalised expansion weights (<= 1, typically 1e-2 forward / 1e-3 backward) are written
+        # scaled by a power of two so that their lo halves stay fp16 normals; undone in the consuming product's alpha
+        fw_sc, bw_sc = (256.0, 4096.0) if x3 else (1.0, 1.0)
         Sp, nqp = -(-S // pad) * pad, -(-nq // pad) * pad
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dv)      # noqa: E731
         zc = lambda *s: torch.zeros(*s, dtype=cdt, device=dv)               # noqa: E731  (K padding must be finite)
         feats2 = feats.reshape(M, F)
         if not feats2.is_contiguous():
             feats2 = feats2.contiguous()
-        x0 = ops.gemm(self._as_operand(feats2, M, F, F), self.in_w, self.in_b, out_dtype=torch.float32)   # [M,d]
+        x0 = ops.gemm(self._as_operand(feats2, M, F, F), self.in_w, self.in_b, out_dtype=torch.float32,
+                      alpha=self.in_a)                                                                   # [M,d]
         xcat = f(M, L * d)
         z = f(B, nq, S)
         pf, nf = zc(B, nq, Sp), zc(B, nq, Sp)
@@ -338,34 +366,35 @@ class CaptionerEngine:
             xin, ldin = (x0, d) if i == 0 else (xcat[:, (i - 1) * d:], ld)
             xo = xcat[:, i * d:]
             x2 = ops.layernorm(xin, w["n1w"], w["n1b"], M=M, C_=d, ldx=ldin, out_dtype=cdt)
-            ops.gemm(x2, w["key_w"], w["key_b"], out=key)
-            sel = ops.gemm(x2, w["sel_w"], w["sel_b"], out_dtype=torch.float32)
+            ops.gemm(x2, w["key_w"], w["key_b"], out=key, alpha=w["key_a"])
+            sel = ops.gemm(x2, w["sel_w"], w["sel_b"], out_dtype=torch.float32, alpha=w["sel_a"])
             # (class_a | class_b) projections, produced transposed: [B, 2d, S] = W·x2ᵀ + b(row)
             ops.gemm(w["ab_w"], x2, w["ab_b"], out=vabT, bias_axis=1, M=2 * d, N=S, K=d, lda=d, ldw=d, ldc=Sp,
-                     batch=B, strideA=0, strideW=S * d, strideC=2 * d * Sp)
+                     batch=B, strideA=0, strideW=S * d, strideC=2 * d * Sp, alpha=w["ab_a"])
             # z = Q·Kᵀ/sqrt(d)
-            ops.gemm(w["q"], key, out=z, alpha=1.0 / math.sqrt(d), M=nq, N=S, K=d, lda=d, ldw=d, ldc=S,
+            ops.gemm(w["q"], key, out=z, alpha=w["q_a"] / math.sqrt(d), M=nq, N=S, K=d, lda=d, ldw=d, ldc=S,
                      batch=B, strideA=0, strideW=S * d, strideC=nq * S)
-            ops.stcexp_normalize(z, enc_len, self.group_meta, len(g.num_exp_enc_list), pf, nf, pb, nb, colsum)
+            ops.stcexp_normalize(z, enc_len, self.group_meta, len(g.num_exp_enc_list), pf, nf, pb, nb, colsum,
+                                 scale_fw=fw_sc, scale_bw=bw_sc)
             # class_aᵀ [d,nq] = Vaᵀ·pos_fwᵀ + Bvᵀ    (layers.py:63-64, transposed)
             ops.gemm(vabT, pf, residual=w["bvT"], out=AT, M=d, N=nq, K=Sp, lda=Sp, ldw=Sp, ldr=nq, ldc=nqp, batch=B,
-                     strideA=2 * d * Sp, strideW=nq * Sp, strideR=0, strideC=d * nqp)
+                     strideA=2 * d * Sp, strideW=nq * Sp, strideR=0, strideC=d * nqp, alpha=1.0 / fw_sc)
             ops.gemm(vabT[:, d:], nf, residual=w["bvT"], out=BT, M=d, N=nq, K=Sp, lda=Sp, ldw=Sp, ldr=nq, ldc=nqp,
-                     batch=B, strideA=2 * d * Sp, strideW=nq * Sp, strideR=0, strideC=d * nqp)
+                     batch=B, strideA=2 * d * Sp, strideW=nq * Sp, strideR=0, strideC=d * nqp, alpha=1.0 / fw_sc)
             # backward: [S,nq]·[nq,d]
             ops.gemm(pb, AT, out=A2, M=S, N=d, K=nqp, lda=nqp, ldw=nqp, ldc=d, batch=B, strideA=S * nqp,
-                     strideW=d * nqp, strideC=S * d)
+                     strideW=d * nqp, strideC=S * d, alpha=1.0 / bw_sc)
             ops.gemm(nb, BT, out=B2, M=S, N=d, K=nqp, lda=nqp, ldw=nqp, ldc=d, batch=B, strideA=S * nqp,
-                     strideW=d * nqp, strideC=S * d)
+                     strideW=d * nqp, strideC=S * d, alpha=1.0 / bw_sc)
             ops.selector_mix(xin, ldin, sel, d, A2, d, B2, d, xo, ld, M, d)
             x2 = ops.layernorm(xo, w["n2w"], w["n2b"], M=M, C_=d, ldx=ld, out_dtype=cdt)
-            h = ops.gemm(x2, w["f1w"], w["f1b"], act=ops.ACT_RELU)
+            h = ops.gemm(x2, w["f1w"], w["f1b"], act=ops.ACT_RELU, alpha=w["f1a"])
             ops.gemm(h, w["f2w"], w["f2b"], residual=xo, out=xo, M=M, N=d, K=g.ff, lda=g.ff, ldw=g.ff, ldr=ld,
-                     ldc=ld)
+                     ldc=ld, alpha=w["f2a"])
         pre = ops.gemm(self._as_operand(xcat, M, ld, ld), self.er_w, self.er_b, residual=xcat[:, (L - 1) * d:], M=M,
-                       N=d, K=ld, lda=ld, ldw=ld, ldr=ld, ldc=d, out=f(M, d))
+                       N=d, K=ld, lda=ld, ldw=ld, ldr=ld, ldc=d, out=f(M, d), alpha=self.er_a)
         mem = ops.layernorm(pre, self.ern_w, self.ern_b).view(B, S, d)
-        if want_bf16_mem and cdt == torch.bfloat16:
+        if want_bf16_mem and cdt != torch.float32:                 # the K/V projection's operand, rounded once
             return mem, ops.layernorm(pre, self.ern_w, self.ern_b, out_dtype=cdt).view(B, S, d)
         return mem
 
@@ -384,7 +413,7 @@ class CaptionerEngine:
         # bit-identical K/V: round-to-nearest-even of the same fp32 values either way.
         if a.dtype != self.kv_w.dtype:
             a = self._as_operand(a, B * S, d, d)
-        ops.gemm(a, self.kv_w, self.kv_b, out=out, M=B * S, N=n, K=d, lda=d, ldw=d, ldc=n)
+        ops.gemm(a, self.kv_w, self.kv_b, out=out, M=B * S, N=n, K=d, lda=d, ldw=d, ldc=n, alpha=self.kv_a)
         return out
 
     # ------------------------------------------------------------------------------------------

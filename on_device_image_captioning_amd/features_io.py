@@ -117,14 +117,18 @@ class FeatureStore:
         use_pinned = self._pinned is not None and B <= self._pinned[0].shape[0] and smax <= self._pinned[0].shape[1]
         if use_pinned:
             self._ev[self._turn].synchronize()                   # the upload that last used this buffer is done
-            host = self._pinned[self._turn][:B, :smax]
+            # a CONTIGUOUS [B, smax, F] region at the head of the pinned slab: a strided view ([:B, :smax] of
+            # [max_batch, max_tokens, F]) would be uploaded through a pageable temporary, i.e. synchronously, and the
+            # event below would guard a buffer the DMA never read
+            host = self._pinned[self._turn].view(-1)[:B * smax * self.feat_dim].view(B, smax, self.feat_dim)
         else:
             host = torch.empty(B, smax, self.feat_dim)
+        dst = host.numpy()                                       # shares memory; np.copyto reads the read-only memmap
         for b, (off, n) in enumerate(spans):
             src = np.frombuffer(self._mm, dtype="<f4", count=n * self.feat_dim, offset=off).reshape(n, self.feat_dim)
-            host[b, :n] = torch.from_numpy(src)
+            np.copyto(dst[b, :n], src)
             if n < smax:
-                host[b, n:] = 0.0
+                dst[b, n:] = 0.0
         if self.device is None:
             return host.clone() if use_pinned else host, pads
         out = host.to(self.device, non_blocking=True)

@@ -13,11 +13,15 @@ from typing import Optional, Sequence
 import torch
 
 from . import _hip
-from ._hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F16, F32, FP8  # noqa: F401  (re-exported)
+from ._hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F16, F32, FP8, H2  # noqa: F401  (re-exported)
 
 FP8_DTYPE = torch.float8_e4m3fn          # OCP e4m3: the fp8 format of gfx950's MFMA
 FP8_MAX = 448.0
-_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16, FP8_DTYPE: FP8}
+# Split-fp16 tensors (ODIC_H2: hi + lo fp16 pairs, 4 bytes per element in [8 hi | 8 lo] groups — include/odic_hip.h)
+# travel as torch.int32 tensors of the LOGICAL shape: same sizes, strides and zero bytes as the fp32 tensor they
+# replace, and a dtype no other operand of this library uses.
+H2_DTYPE = torch.int32
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16, FP8_DTYPE: FP8, H2_DTYPE: H2}
 
 
 def _stream() -> C.c_void_p:
@@ -145,6 +149,7 @@ class autotune:
 
 
 _LOWP_CANDIDATES = (0, 1, 2, 3, 4)          # gemm_lowp.hip tile configurations (fp8 / fp16 operands)
+_X3_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_X3_TILE_CANDIDATES", "0,1,2,3").split(","))   # gemm_x3.hip
 
 
 def _tune_gemm(args: "_hip.GemmArgs", key, out: torch.Tensor, candidates=None) -> int:
@@ -229,7 +234,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
                       _p(ln_fold[0]) if ln_fold else None, float(ln_fold[1]) if ln_fold else 0.0, None,
                       _p(col_scale), float(out_scale), _p(out16), out16.stride(0) if out16 is not None else 0,
                       _p(stats_out), _p(ln_stats))
-    if A.dtype in (torch.bfloat16, torch.float16, FP8_DTYPE):
+    if A.dtype in (torch.bfloat16, torch.float16, FP8_DTYPE, H2_DTYPE):
         if batch == 1 and A.dtype == torch.bfloat16:
             a.workspace = _gemm_workspace(A.device).data_ptr()
         key = (A.dtype, M, N, K, batch, out.dtype, act, residual is not None, out16 is not None, ln_stats is not None)
@@ -240,14 +245,16 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
                 _TILE_CHOICE[key] = cfg
         if cfg is None and _TUNING and _PROFILE is None and ldc == N and batch == 1 \
                 and not torch.cuda.is_current_stream_capturing():
-            cfg = _tune_gemm(a, key, out, None if A.dtype == torch.bfloat16 else _LOWP_CANDIDATES)
+            cfg = _tune_gemm(a, key, out, None if A.dtype == torch.bfloat16 else
+                             (_X3_CANDIDATES if A.dtype == H2_DTYPE else _LOWP_CANDIDATES))
         if cfg is not None:
             a.tile_cfg = cfg
     isz, osz = A.element_size(), out.element_size()
     nbytes = batch * ((M * K if strideA or batch == 1 else M * K / batch) * isz +
                       (N * K if strideW or batch == 1 else N * K / batch) * isz + M * N * osz +
                       (M * N * 4 if residual is not None else 0))
-    fam = {torch.bfloat16: "gemm_bf16", torch.float16: "gemm_f16", FP8_DTYPE: "gemm_fp8"}.get(A.dtype, "gemm_f32")
+    fam = {torch.bfloat16: "gemm_bf16", torch.float16: "gemm_f16", FP8_DTYPE: "gemm_fp8",
+           H2_DTYPE: "gemm_x3"}.get(A.dtype, "gemm_f32")
     with _timed(fam, 2.0 * M * N * K * batch, nbytes,
                 f"{M}x{N}x{K}" + (f"x{batch}" if batch > 1 else "")):
         _hip.check(_hip.load().odic_gemm(C.byref(a), _stream()), "odic_gemm")
@@ -301,6 +308,48 @@ def cast_bf16(x: torch.Tensor, *, M: Optional[int] = None, C_: Optional[int] = N
     with _timed("cast_bf16", 0.0, M * C_ * 6.0):
         _hip.check(_hip.load().odic_cast_f32_to_bf16(_p(x), ldx, _p(out), C_, M, C_, _stream()), "odic_cast_f32_to_bf16")
     return out
+
+
+def cast_h2(x: torch.Tensor, *, M: Optional[int] = None, C_: Optional[int] = None, ldx: Optional[int] = None
+            ) -> torch.Tensor:
+    """fp32 [M,C] (row stride ldx) → contiguous split-fp16 [M,C] (an int32 tensor, see H2_DTYPE)."""
+    _need_cuda(x)
+    if M is None:
+        C_ = x.shape[-1]
+        M = x.numel() // C_
+        ldx = C_
+    out = torch.empty((M, C_), dtype=H2_DTYPE, device=x.device)
+    with _timed("cast_h2", 0.0, M * C_ * 8.0):
+        _hip.check(_hip.load().odic_cast_f32_to_h2(_p(x), ldx, _p(out), C_, M, C_, _stream()), "odic_cast_f32_to_h2")
+    return out
+
+
+def h2_from_f32(x: torch.Tensor) -> torch.Tensor:
+    """Weight-pack-time split of an fp32 tensor [..., K] (K % 8 == 0) into the h2 layout, on the tensor's device with
+    plain torch ops (exact: two round-to-nearest-even fp16 conversions)."""
+    if x.shape[-1] % 8:
+        raise RuntimeError("h2 rows are whole groups of 8 elements")
+    x = x.detach().float().clamp(-65504.0, 65504.0)
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    g = torch.stack([hi.reshape(*x.shape[:-1], -1, 8), lo.reshape(*x.shape[:-1], -1, 8)], dim=-2)   # [..., K/8, 2, 8]
+    return g.contiguous().view(torch.int32).reshape(x.shape)
+
+
+def h2_to_f32(t: torch.Tensor) -> torch.Tensor:
+    """Inverse of h2_from_f32 (tests, taps): hi + lo in fp32."""
+    g = t.contiguous().view(torch.float16).reshape(*t.shape[:-1], -1, 2, 8).float()
+    return (g[..., 0, :] + g[..., 1, :]).reshape(t.shape)
+
+
+def pow2_scale_for_h2(w: torch.Tensor) -> float:
+    """Power of two s such that max|w|·s lies in [2^12, 2^13): the hi parts sit far from the fp16 overflow and the lo
+    parts (|lo| <= |w|·s·2^-11) of all but negligible elements stay fp16 normals.  Exact to undo (alpha = 1/s)."""
+    import math
+    m = float(w.detach().abs().max())
+    if not (m > 0.0) or not math.isfinite(m):
+        return 1.0
+    return float(2.0 ** (12 - math.floor(math.log2(m))))
 
 
 def copy(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
@@ -368,8 +417,9 @@ def window_attention(qkv: torch.Tensor, bias_table: torch.Tensor, B: int, res: i
     # algorithmic work per (window, head): QKᵀ + PV = 4·N²·hd FLOP; q,k,v in + o out = 4·N·hd elements
     inst = B * (res // ws) ** 2 * heads
     n = ws * ws
-    with _timed("window_attention_bf16" if qkv.dtype in (torch.bfloat16, torch.float16) else "window_attention_f32",
-                inst * 4.0 * n * n * 32, inst * 4.0 * n * 32 * qkv.element_size(), f"res{res}h{heads}"):
+    fam = ("window_attention_bf16" if qkv.dtype in (torch.bfloat16, torch.float16) else
+           "window_attention_x3" if qkv.dtype == H2_DTYPE else "window_attention_f32")
+    with _timed(fam, inst * 4.0 * n * n * 32, inst * 4.0 * n * 32 * qkv.element_size(), f"res{res}h{heads}"):
         _hip.check(_hip.load().odic_window_attention(_p(qkv), _p(bias_table), _p(bias_shifted_prescaled), _p(out), B, res, C_,
                                                      heads, ws, shift,
                                                      scale, dtype_code(qkv.dtype), _stream()),
@@ -389,8 +439,10 @@ def stcexp_group_meta(groups: Sequence[int], device) -> torch.Tensor:
 
 def stcexp_normalize(z: torch.Tensor, enc_len: torch.Tensor, group_meta: torch.Tensor, ngroups: int,
                      pos_fw: torch.Tensor, neg_fw: torch.Tensor, pos_bw: torch.Tensor, neg_bw: torch.Tensor,
-                     colsum_ws: torch.Tensor, *, eps: float = 1e-9) -> None:
-    """Outputs may be fp32 or bf16 and wider than (S / nq): padding columns are zero-filled."""
+                     colsum_ws: torch.Tensor, *, eps: float = 1e-9, scale_fw: float = 1.0, scale_bw: float = 1.0) -> None:
+    """Outputs may be fp32, bf16 or split fp16 and wider than (S / nq): padding columns are zero-filled.  scale_fw /
+    scale_bw multiply the forward / backward tables (powers of two that keep a split-fp16 table's lo halves in the
+    fp16 normal range; the consumer undoes them in its alpha)."""
     _need_cuda(z, enc_len, group_meta, pos_fw, neg_fw, pos_bw, neg_bw, colsum_ws)
     B, nq, S = z.shape
     # algorithmic bytes: z read once, the four normalised weight tables written once (incl. their zero K padding)
@@ -399,7 +451,7 @@ def stcexp_normalize(z: torch.Tensor, enc_len: torch.Tensor, group_meta: torch.T
                 B * nq * S * 4.0 + 2.0 * B * nq * pos_fw.shape[-1] * osz + 2.0 * B * S * pos_bw.shape[-1] * osz):
         _hip.check(_hip.load().odic_stcexp_normalize(_p(z), _p(enc_len), _p(group_meta), ngroups, _p(pos_fw),
                                                      _p(neg_fw), pos_fw.shape[-1], _p(pos_bw), _p(neg_bw),
-                                                     pos_bw.shape[-1], _p(colsum_ws), B, nq, S, eps,
+                                                     pos_bw.shape[-1], _p(colsum_ws), B, nq, S, eps, scale_fw, scale_bw,
                                                      dtype_code(pos_fw.dtype), _stream()), "odic_stcexp_normalize")
 
 
@@ -414,8 +466,8 @@ def selector_mix(x, ldx, sel_pre, lds, a, lda, b, ldb, out, ldo, M, d) -> None:
 def dec_embed(tokens, embed, pos_table, pos, y, ldy, N, d, scale) -> None:
     _need_cuda(tokens, embed, pos_table, pos, y)
     with _timed("dec_embed", 2.0 * N * d, N * (8.0 + 2 * d * 4) + d * 4):     # token id, embedding row in, y row out, one pos row
-        _hip.check(_hip.load().odic_dec_embed(_p(tokens), _p(embed), _p(pos_table), _p(pos), _p(y), ldy, N, d, scale,
-                                              _stream()), "odic_dec_embed")
+        _hip.check(_hip.load().odic_dec_embed(_p(tokens), _p(embed), _p(pos_table), _p(pos), _p(y), ldy, N, d,
+                                              pos_table.shape[0], scale, _stream()), "odic_dec_embed")
 
 
 def dynexp_step(lin, ldlin, qexp, bexp, cond_c, key_c, va_c, vb_c, wfa_c, wfb_c, qk_c, anc, row_valid, pos,
@@ -485,7 +537,7 @@ def topk_rows(logp: torch.Tensor, top_val: torch.Tensor, top_idx: torch.Tensor, 
 def embed_args(embed, pos_table, y, ldy, d, scale) -> "_hip.EmbedArgs":
     """odic_embed_args for beam_step / beam_search_step / beam_reset (the caller keeps the tensors alive)."""
     _need_cuda(embed, pos_table, y)
-    return _hip.EmbedArgs(_p(embed), _p(pos_table), _p(y), ldy, d, scale)
+    return _hip.EmbedArgs(_p(embed), _p(pos_table), _p(y), ldy, d, scale, pos_table.shape[0])
 
 
 def _emb_ref(emb):

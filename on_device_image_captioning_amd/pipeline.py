@@ -164,7 +164,7 @@ class CaptionPipeline:
     def _encode(self, e: int = 0) -> None:
         for mi, (swin, cap) in enumerate(self.members):
             feats = swin.forward(self.imgs[e], out_dtype=cap.cdt) if swin is not None else self.imgs[e]
-            if cap.cdt == torch.bfloat16:
+            if cap.cdt != torch.float32:                          # bf16 / split-fp16 encoder: K/V from the rounded memory
                 _, mem16 = cap.encode(feats, self.enc_lens[e], want_bf16_mem=True)
                 cap.project_kv(mem16, out=self.kv_stages[e][mi])
             else:

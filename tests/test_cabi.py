@@ -61,7 +61,7 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.odic_beam_step(16, 16, ctypes.byref(st), None, 4, 17, 20, 77, None) == -1
     assert lib.odic_beam_search_step(16, 100, 100, ctypes.byref(st), None, 4, 3, 129, 77, None) == -1
     assert lib.odic_beam_search_step(None, 100, 100, ctypes.byref(st), None, 4, 3, 20, 77, None) == -2
-    emb = _hip.EmbedArgs(16, 16, None, 512, 512, 1.0)              # embedding tail asked for without an output
+    emb = _hip.EmbedArgs(16, 16, None, 512, 512, 1.0, 20)             # embedding tail asked for without an output
     assert lib.odic_beam_step(16, 16, ctypes.byref(st), ctypes.byref(emb), 4, 3, 20, 77, None) == -2
     assert lib.odic_beam_reset(None, None, 4, 3, 20, 79, None) == -2
     assert lib.odic_copy(16, 32, 24, None) == -1 and lib.odic_copy(None, 32, 32, None) == -2
