@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--beam", type=int, default=None)
     ap.add_argument("--max-len", type=int, default=None)
     ap.add_argument("--shard", type=int, default=None, help="coco5k: images per rank per step")
-    ap.add_argument("--precision", default=None, choices=["bf16", "fp32", "fp8"])
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp32", "fp8", "x3"])
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -268,7 +268,9 @@ def roofline_entry(name, d, workload=None):
     mfma = name.startswith("gemm") or name.startswith("swin_attention_block")
     if mfma:
         # (the non-scaled fp8 MFMA issues at the bf16 rate, MI355X_MICROARCH.md § Matrix cores: priced against 2.5 PF)
-        peak = PEAK["mfma_f32_tflops"] if name == "gemm_f32" else PEAK["mfma_bf16_tflops"]
+        # gemm_x3 (split fp16): three fp16 MFMAs per algorithmic product → priced against a third of the fp16 peak
+        peak = PEAK["mfma_f32_tflops"] if name == "gemm_f32" else \
+            round(PEAK["mfma_bf16_tflops"] / 3.0, 1) if name == "gemm_x3" else PEAK["mfma_bf16_tflops"]
         ach = d["flops"] / sec / 1e12
         e = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
              "frac": round(ach / peak, 4), "algorithmic_flops_per_step": d["flops"]}
