@@ -302,7 +302,10 @@ __global__ __launch_bounds__(DYN_NT) void dynexp_step_kernel(DynParams p) {
 //            NB accumulators; key groups combined through LDS.
 // kv: [n_img, S, ldkv], K at koff, V at voff.
 // ---------------------------------------------------------------------------------------------
-template <int NB>
+// PF (diagnostic builds only, -DODIC_XATTN_VARIANTS, tools/xattn_ab.py): the software-pipelined P·V loop of round 2 —
+// the first batch of V rows requested before the score phase, the next batch under the current batch's FMAs — whose
+// results differed from this kernel's 30 times in 96,000 captions beside the encode graph.
+template <int NB, bool PF = false>
 __global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __restrict__ q, long ldq,
                                                               const float* __restrict__ kv, long ldkv, int koff,
                                                               int voff, const int* __restrict__ enc_len,
@@ -336,6 +339,13 @@ __global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __res
 #pragma unroll
   for (int b = 0; b < NB; ++b) valid[b] = row_valid[n0 + min(b, nb - 1)];
 
+  float vpre[12];
+  if constexpr (PF) {       // V rows of the first P·V batch requested now: their latency passes under scores + softmax
+    const int c_ = tid % dk, g_ = tid / dk, ng_ = 256 / dk;
+    const float* vp_ = kvb + voff + h * dk + c_;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) vpre[i] = vp_[(long)min(g_ + i * ng_, S - 1) * ldkv];
+  }
   // ---- scores: wave w takes sweeps w, w+4, ...; up to 3 sweeps of K loads in flight
   const int nsweep = (S + kps - 1) / kps;
   for (int sw0 = wave; sw0 < nsweep; sw0 += 12) {
@@ -388,8 +398,17 @@ __global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __res
   const float* vp = kvb + voff + h * dk + c;
   for (int s0 = g; s0 < S; s0 += 12 * ng) {
     float v[12];
+    if constexpr (PF) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) v[i] = vp[(long)min(s0 + i * ng, S - 1) * ldkv];
+      for (int i = 0; i < 12; ++i) v[i] = vpre[i];
+      if (s0 + 12 * ng < S) {                        // next batch in flight under this one's FMAs
+#pragma unroll
+        for (int i = 0; i < 12; ++i) vpre[i] = vp[(long)min(s0 + 12 * ng + i * ng, S - 1) * ldkv];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) v[i] = vp[(long)min(s0 + i * ng, S - 1) * ldkv];
+    }
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       const int s = s0 + i * ng;
@@ -1175,3 +1194,78 @@ extern "C" int odic_logsoftmax_sample(const float* logits, int64_t ldl, float* l
   else hipLaunchKernelGGL(logsoftmax_sample_kernel<16>, dim3(N), dim3(1024), 0, s, logits, (long)ldl, logp_out, (long)ldp, top_val, top_idx, V, k, (unsigned long long)seed, pos);
   return odic_launch_status();
 }
+
+#ifdef ODIC_XATTN_VARIANTS
+// =================================================================================================
+// Diagnostic build only (tools/xattn_ab.py → tools/_build/libodic_dbg.so; never part of libodic_hip.so): the two forms
+// of the cross-attention step side by side on the SAME inputs inside the real pipeline, every output element compared
+// on the device, and the operands of the first mismatch kept for the post-mortem.
+// =================================================================================================
+namespace {
+struct DbgState { int count; int first_site; int row; int col; int snapped; int launches; int pad[2]; };
+
+__global__ __launch_bounds__(256) void dbg_compare_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,
+                                                          int ld, int d, int site, DbgState* st) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) atomicAdd(&st->launches, 1);
+  if (i >= n) return;
+  const int r = i / d, c = i - r * d;
+  const unsigned x = __float_as_uint(a[(long)r * ld + c]), y = __float_as_uint(b[(long)r * ld + c]);
+  if (x != y) {
+    atomicAdd(&st->count, 1);
+    if (atomicCAS(&st->first_site, -1, site) == -1) { st->row = r; st->col = c; }
+  }
+}
+// one block: if this site holds the first mismatch and nothing was kept yet, keep q / both outputs of the image's beams
+// and the K / V columns [koff, koff + d) / [voff, voff + d) of the image
+__global__ __launch_bounds__(256) void dbg_snapshot_kernel(const float* q, long ldq, const float* kv, long ldkv, int koff,
+                                                           int voff, const float* a, const float* b, long ldo, int beams,
+                                                           int S, int d, int site, DbgState* st, float* snap) {
+  if (st->first_site != site || st->snapped) return;
+  __syncthreads();
+  const int img = st->row / beams;
+  float* sq = snap; float* sa = sq + beams * d; float* sb = sa + beams * d; float* sk = sb + beams * d; float* sv = sk + (long)S * d;
+  for (int i = threadIdx.x; i < beams * d; i += 256) {
+    const int r = i / d, c = i - r * d;
+    sq[i] = q[(long)(img * beams + r) * ldq + c];
+    sa[i] = a[(long)(img * beams + r) * ldo + c];
+    sb[i] = b[(long)(img * beams + r) * ldo + c];
+  }
+  for (int i = threadIdx.x; i < S * d; i += 256) {
+    const int s_ = i / d, c = i - s_ * d;
+    sk[i] = kv[((long)img * S + s_) * ldkv + koff + c];
+    sv[i] = kv[((long)img * S + s_) * ldkv + voff + c];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) st->snapped = 1;
+}
+}  // namespace
+
+// variant 0 = the shipped kernel, 1 = the round-2 software-pipelined form
+extern "C" int odic_dbg_cross_attn_step(int variant, const float* q, int64_t ldq, const float* kv, int64_t ldkv, int32_t koff,
+                                        int32_t voff, const int32_t* enc_len, const int32_t* row_valid, float* out,
+                                        int64_t ldo, int32_t N, int32_t n_img, int32_t S, int32_t d, int32_t heads,
+                                        void* stream) {
+  const int beams = N / n_img;
+  if (beams != 3 || d / heads != 64) return ODIC_EUNSUPPORTED;
+  const size_t sh = (size_t)(3 * S + 256 * 3 + 3) * sizeof(float);
+  if (variant == 0)
+    hipLaunchKernelGGL((cross_attn_step_kernel<3, false>), dim3(n_img, heads, 1), dim3(256), sh, (hipStream_t)stream, q,
+                       (long)ldq, kv, (long)ldkv, koff, voff, enc_len, row_valid, out, (long)ldo, beams, S, d, heads);
+  else
+    hipLaunchKernelGGL((cross_attn_step_kernel<3, true>), dim3(n_img, heads, 1), dim3(256), sh, (hipStream_t)stream, q,
+                       (long)ldq, kv, (long)ldkv, koff, voff, enc_len, row_valid, out, (long)ldo, beams, S, d, heads);
+  return odic_launch_status();
+}
+// state: int32[8] zeroed by the caller ({count, first_site = -1, ...}); snap: fp32 [3·beams·d + 2·S·d]
+extern "C" int odic_dbg_compare_snapshot(const float* a, const float* b, int64_t ldo, const float* q, int64_t ldq,
+                                         const float* kv, int64_t ldkv, int32_t koff, int32_t voff, int32_t N, int32_t n_img,
+                                         int32_t S, int32_t d, int32_t site, void* state, float* snap, void* stream) {
+  const int n = N * d;
+  hipLaunchKernelGGL(dbg_compare_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b, n, (int)ldo, d,
+                     site, (DbgState*)state);
+  hipLaunchKernelGGL(dbg_snapshot_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q, (long)ldq, kv, (long)ldkv, koff,
+                     voff, a, b, (long)ldo, N / n_img, S, d, site, (DbgState*)state, snap);
+  return odic_launch_status();
+}
+#endif  // ODIC_XATTN_VARIANTS

@@ -439,6 +439,33 @@ def run_shard(pipe: CaptionPipeline, n_local: int, fetch, pad_idx: int) -> Tuple
     return toks, lens
 
 
+def run_steps(pipe: CaptionPipeline, ring: Sequence[torch.Tensor], n_steps: int, pad_idx: int
+              ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`n_steps` batches (ring[i % len(ring)]) through the software pipeline with the FINISHED token rows kept on the
+    device: → (tokens int32 [n_steps·B, T] padded with pad_idx, lengths int32 [n_steps·B]) in submission order — the
+    operands of ONE gather_captions at the end of a multi-GPU run (the north star's "gather of finished token-ID
+    tensors"; a collective per step would synchronise the ranks every few milliseconds)."""
+    B, T = pipe.B, pipe.T
+    toks = torch.full((n_steps * B, T), pad_idx, dtype=torch.int32, device=pipe.device)
+    lens = torch.zeros(n_steps * B, dtype=torch.int32, device=pipe.device)
+    got = 0
+
+    def take():
+        nonlocal got
+        t, l = pipe.collect_device()
+        toks[got * B:(got + 1) * B] = t
+        lens[got * B:(got + 1) * B] = l
+        got += 1
+
+    for i in range(n_steps):
+        while pipe.full():
+            take()
+        pipe.submit(ring[i % len(ring)])
+    while got < n_steps:
+        take()
+    return toks, lens
+
+
 def caption_sharded(caption_batch, n_items: int, fetch, batch: int, T: int, eos_idx: int, device,
                     rank: int, world: int, group=None) -> List[List[int]]:
     """Evaluate `n_items` images split over `world` ranks.

@@ -50,3 +50,28 @@ def test_more_ranks_than_gpus_is_refused():
     if torch.cuda.device_count() >= 2:
         pytest.skip("enough GPUs here")
     assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_gpu_count_comes_from_sysfs_not_from_hip(tmp_path, monkeypatch):
+    """The launcher parent counts GPUs from the KFD topology (CPU nodes have simd_count 0) and the *_VISIBLE_DEVICES
+    variables — it never imports torch or touches the HIP runtime (VERDICT r2 #8b)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):          # two CPU sockets, three GPUs
+        d = tmp_path / "nodes" / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    root = str(tmp_path / "nodes")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpus_without_hip(root) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpus_without_hip(root) == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert bench.visible_gpus_without_hip(root) == 1
+    assert bench.visible_gpus_without_hip(str(tmp_path / "absent"), str(tmp_path / "no_kfd")) == 0
+    (tmp_path / "kfd").write_text("")
+    assert bench.visible_gpus_without_hip(str(tmp_path / "absent"), str(tmp_path / "kfd")) is None
+    src = open(BENCH).read()
+    body = src[src.index("def spawn_ranks"):src.index("# model / pipeline")]
+    assert "import torch" not in body and "device_count" not in body

@@ -136,3 +136,34 @@ def test_run_shard_pipelined_two_ranks(tmp_path, n_items, batch):
         assert d["caps"] == want, f"rank {r}"
         if n_items / world / batch > 3:
             assert d["max_outstanding"] == 3                # the ring was kept full
+
+
+def _worker_run_steps(rank, world, port, n_steps, batch, out_dir):
+    sys.path.insert(0, ROOT)
+    from on_device_image_captioning_amd.pipeline import gather_captions, run_steps
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a ring of 3 distinct batches per rank; image id = 1000·rank + 10·ring slot + row
+    ring = [(torch.arange(batch, dtype=torch.float32) + 1000 * rank + 10 * j).view(batch, 1, 1, 1).expand(batch, 3, 2, 2)
+            .contiguous() for j in range(3)]
+    pipe = _FakePipe(batch)
+    toks, lens = run_steps(pipe, ring, n_steps, EOS)
+    assert toks.shape == (n_steps * batch, T) and pipe.max_outstanding == min(3, n_steps) and not pipe.q
+    caps = gather_captions(toks, lens, n_steps * batch * world)          # ONE collective per run
+    torch.save(caps, os.path.join(out_dir, f"t{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_steps,batch", [(5, 4), (1, 16), (7, 3)])
+def test_e2e16_gather_once_per_run_two_ranks(tmp_path, n_steps, batch):
+    """bench.py's e2e16 step under N > 1: the token rows of all steps stay on the device and ONE all_gather at the end
+    returns them rank-major, in submission order — rank r's last step is rows [(r·n + n − 1)·B, (r·n + n)·B)."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_run_steps, args=(world, port, n_steps, batch, str(tmp_path)), nprocs=world, join=True)
+    want = [fake_caption(1000 * r + 10 * (i % 3) + b) for r in range(world) for i in range(n_steps) for b in range(batch)]
+    for r in range(world):
+        assert torch.load(os.path.join(str(tmp_path), f"t{r}.pt")) == want, f"rank {r}"
