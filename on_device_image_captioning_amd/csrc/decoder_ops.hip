@@ -305,7 +305,10 @@ __global__ __launch_bounds__(DYN_NT) void dynexp_step_kernel(DynParams p) {
 // PF (diagnostic builds only, -DODIC_XATTN_VARIANTS, tools/xattn_ab.py): the software-pipelined P·V loop of round 2 —
 // the first batch of V rows requested before the score phase, the next batch under the current batch's FMAs — whose
 // results differed from this kernel's 30 times in 96,000 captions beside the encode graph.
-template <int NB, bool PF = false>
+//   PF = 1 as round 2 wrote it; 2..4 = the same with ONE change each, to locate the mechanism on the hardware:
+//   2: `s_nop 7` after every group of P·V FMAs; 3: the FMAs kept scalar (no v_pk_fma_f32); 4: all of a key's
+//   probabilities read and waited for (lgkmcnt(0)) before the first FMA.
+template <int NB, int PF = 0>
 __global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __restrict__ q, long ldq,
                                                               const float* __restrict__ kv, long ldkv, int koff,
                                                               int voff, const int* __restrict__ enc_len,
@@ -413,8 +416,21 @@ __global__ __launch_bounds__(256) void cross_attn_step_kernel(const float* __res
     for (int i = 0; i < 12; ++i) {
       const int s = s0 + i * ng;
       if (s < S) {
+        if constexpr (PF == 4) {
+          float pb[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = fmaf(sc[(b < nb ? b : 0) * S + s], v[i], acc[b]);
+          for (int b = 0; b < NB; ++b) pb[b] = sc[(b < nb ? b : 0) * S + s];
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pb[0]) :: "memory");
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[b] = fmaf(pb[b], v[i], acc[b]);
+        } else {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            acc[b] = fmaf(sc[(b < nb ? b : 0) * S + s], v[i], acc[b]);
+            if constexpr (PF == 3) asm volatile("" : "+v"(acc[b]));
+          }
+          if constexpr (PF == 2) asm volatile("s_nop 7" ::: "memory");
+        }
       }
     }
   }
@@ -1202,18 +1218,21 @@ extern "C" int odic_logsoftmax_sample(const float* logits, int64_t ldl, float* l
 // on the device, and the operands of the first mismatch kept for the post-mortem.
 // =================================================================================================
 namespace {
-struct DbgState { int count; int first_site; int row; int col; int snapped; int launches; int pad[2]; };
+struct DbgState { int count; int first_site; int row; int col; int snapped; int launches; int per_variant[10]; };
 
 __global__ __launch_bounds__(256) void dbg_compare_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,
-                                                          int ld, int d, int site, DbgState* st) {
+                                                          int ld, int d, int site, DbgState* st, int variant) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) atomicAdd(&st->launches, 1);
+  if (i == 0 && variant == 1) atomicAdd(&st->launches, 1);
   if (i >= n) return;
   const int r = i / d, c = i - r * d;
   const unsigned x = __float_as_uint(a[(long)r * ld + c]), y = __float_as_uint(b[(long)r * ld + c]);
   if (x != y) {
-    atomicAdd(&st->count, 1);
-    if (atomicCAS(&st->first_site, -1, site) == -1) { st->row = r; st->col = c; }
+    atomicAdd(&st->per_variant[variant], 1);
+    if (variant == 1) {
+      atomicAdd(&st->count, 1);
+      if (atomicCAS(&st->first_site, -1, site) == -1) { st->row = r; st->col = c; }
+    }
   }
 }
 // one block: if this site holds the first mismatch and nothing was kept yet, keep q / both outputs of the image's beams
@@ -1249,23 +1268,33 @@ extern "C" int odic_dbg_cross_attn_step(int variant, const float* q, int64_t ldq
   const int beams = N / n_img;
   if (beams != 3 || d / heads != 64) return ODIC_EUNSUPPORTED;
   const size_t sh = (size_t)(3 * S + 256 * 3 + 3) * sizeof(float);
-  if (variant == 0)
-    hipLaunchKernelGGL((cross_attn_step_kernel<3, false>), dim3(n_img, heads, 1), dim3(256), sh, (hipStream_t)stream, q,
-                       (long)ldq, kv, (long)ldkv, koff, voff, enc_len, row_valid, out, (long)ldo, beams, S, d, heads);
-  else
-    hipLaunchKernelGGL((cross_attn_step_kernel<3, true>), dim3(n_img, heads, 1), dim3(256), sh, (hipStream_t)stream, q,
-                       (long)ldq, kv, (long)ldkv, koff, voff, enc_len, row_valid, out, (long)ldo, beams, S, d, heads);
+#define ODIC_DBG_X(V)                                                                                                  \
+  hipLaunchKernelGGL((cross_attn_step_kernel<3, V>), dim3(n_img, heads, 1), dim3(256), sh, (hipStream_t)stream, q,       \
+                     (long)ldq, kv, (long)ldkv, koff, voff, enc_len, row_valid, out, (long)ldo, beams, S, d, heads)
+  switch (variant) {
+    case 0: ODIC_DBG_X(0); break;
+    case 1: ODIC_DBG_X(1); break;
+    case 2: ODIC_DBG_X(2); break;
+    case 3: ODIC_DBG_X(3); break;
+    case 4: ODIC_DBG_X(4); break;
+    default: return ODIC_EINVAL;
+  }
+#undef ODIC_DBG_X
   return odic_launch_status();
 }
-// state: int32[8] zeroed by the caller ({count, first_site = -1, ...}); snap: fp32 [3·beams·d + 2·S·d]
+// state: int32[16] from the caller ({count, first_site = -1, row, col, snapped, launches, per_variant[10]});
+// snap: fp32 [3·beams·d + 2·S·d]; variant = which form `b` came from (the snapshot is taken for variant 1 only)
 extern "C" int odic_dbg_compare_snapshot(const float* a, const float* b, int64_t ldo, const float* q, int64_t ldq,
                                          const float* kv, int64_t ldkv, int32_t koff, int32_t voff, int32_t N, int32_t n_img,
-                                         int32_t S, int32_t d, int32_t site, void* state, float* snap, void* stream) {
+                                         int32_t S, int32_t d, int32_t site, void* state, float* snap, int32_t variant,
+                                         void* stream) {
   const int n = N * d;
+  if (variant < 1 || variant > 9) return ODIC_EINVAL;
   hipLaunchKernelGGL(dbg_compare_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b, n, (int)ldo, d,
-                     site, (DbgState*)state);
-  hipLaunchKernelGGL(dbg_snapshot_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q, (long)ldq, kv, (long)ldkv, koff,
-                     voff, a, b, (long)ldo, N / n_img, S, d, site, (DbgState*)state, snap);
+                     site, (DbgState*)state, variant);
+  if (variant == 1)
+    hipLaunchKernelGGL(dbg_snapshot_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q, (long)ldq, kv, (long)ldkv, koff,
+                       voff, a, b, (long)ldo, N / n_img, S, d, site, (DbgState*)state, snap);
   return odic_launch_status();
 }
 #endif  // ODIC_XATTN_VARIANTS

@@ -6,3 +6,4 @@ cd "$(dirname "$0")/.."
 mkdir -p tools/_build
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Wall -Wno-unused-function \
   -DODIC_XATTN_VARIANTS -shared on_device_image_captioning_amd/csrc/decoder_ops.hip -o tools/_build/libodic_dbg.so
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -shared tools/csrc/pkfma_probe.hip -o tools/_build/libpkfma_probe.so
