@@ -10,7 +10,11 @@ int odic_gemm_x3_launch(const odic_gemm_args* a, hipStream_t stream);
 extern "C" int odic_abi_version(void) { return ODIC_ABI_VERSION; }
 
 extern "C" const char* odic_build_info(void) {
+#ifdef ODIC_EXPERIMENTAL_GEMM
+  return "libodic_hip gfx950 (CDNA4) experimental-gemm " __DATE__ " " __TIME__ " hipcc " __clang_version__;
+#else
   return "libodic_hip gfx950 (CDNA4) " __DATE__ " " __TIME__ " hipcc " __clang_version__;
+#endif
 }
 
 extern "C" int odic_gemm(const odic_gemm_args* a, void* stream) {

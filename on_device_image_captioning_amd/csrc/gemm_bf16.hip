@@ -308,6 +308,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && MI * NI == 32) ?
 
 
 
+#ifdef ODIC_EXPERIMENTAL_GEMM   // persistent and 256x256 phase-pipelined kernels: measured, never selected
 // One K-tile of LDS-DMA for the persistent kernel: `buffer_load ... lds` with the tile origins in scalar resource
 // descriptors, per-lane 32-bit offsets and the K advance as the scalar offset.  (A free function: a local of the
 // buffer-resource type inside a lambda of a __global__ template suppresses the kernel's host stub on ROCm 7.2.)
@@ -809,6 +810,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256sq_kernel(Params p) {
   }
 }
 
+#endif  // ODIC_EXPERIMENTAL_GEMM
+
 template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK = 64, bool FOLD = false>
 int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
   constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
@@ -865,6 +868,7 @@ int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
 }
 
 
+#ifdef ODIC_EXPERIMENTAL_GEMM
 template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK = 64>
 int launch_persist(Params& p, int out_dtype, int batch, hipStream_t stream) {
   constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
@@ -944,6 +948,20 @@ int launch_256sq(Params& p, int out_dtype, int batch, hipStream_t stream) {
   return odic_launch_status();
 }
 
+#endif  // ODIC_EXPERIMENTAL_GEMM
+
+// The default build carries the five tile configurations the host's tuner chooses from (0, 1, 7, 10) or the built-in
+// model falls back to (2).  Everything else that was built and measured on the way — more stages, 16-wave and 4-wave
+// 256-wide tiles, out-of-phase residents, the persistent and the 256x256 phase-pipelined kernels, the LayerNorm fold
+// across two products — compiles only with -DODIC_EXPERIMENTAL_GEMM (make EXTRA=-DODIC_EXPERIMENTAL_GEMM): none of it
+// is ever selected, and the folded-LayerNorm consumer is the one place where hipcc emits v_pk_fma_f32 with op_sel
+// source selection, the instruction form behind the round-2 wrong-row incident.
+#ifdef ODIC_EXPERIMENTAL_GEMM
+constexpr bool kFold = true;
+#else
+constexpr bool kFold = false;
+#endif
+
 }  // namespace
 
 int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
@@ -985,17 +1003,18 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     cfg = (c0 <= c1 && c0 <= c2) ? 0 : (c1 <= c2 ? 1 : 2);
   }
   switch (cfg) {
-    case 0: return launch_cfg<2, 2, 4, 2, 2, 64, true>(p, a->out_dtype, a->batch, stream);     // 128 x 64, 2 stages
-    case 1: return launch_cfg<2, 2, 4, 4, 2, 64, true>(p, a->out_dtype, a->batch, stream);     // 128 x 128
+    case 0: return launch_cfg<2, 2, 4, 2, 2, 64, kFold>(p, a->out_dtype, a->batch, stream);     // 128 x 64, 2 stages
+    case 1: return launch_cfg<2, 2, 4, 4, 2, 64, kFold>(p, a->out_dtype, a->batch, stream);     // 128 x 128
     case 2: return launch_cfg<2, 4, 8, 4, 2>(p, a->out_dtype, a->batch, stream);     // 256 x 256
+    case 7: return launch_cfg<4, 2, 4, 4, 2, 32, kFold>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32 (48 KiB)
+    case 10: return launch_cfg<4, 2, 4, 4, 3, 32, kFold>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32, 3 stages (72 KiB)
+#ifdef ODIC_EXPERIMENTAL_GEMM
     case 3: return launch_cfg<2, 2, 4, 2, 3>(p, a->out_dtype, a->batch, stream);     // 128 x 64, 3 stages
     case 4: return launch_cfg<2, 2, 4, 4, 3>(p, a->out_dtype, a->batch, stream);     // 128 x 128, 3 stages
     case 5: return launch_cfg<4, 2, 4, 4, 3>(p, a->out_dtype, a->batch, stream);     // 256 x 128, 3 stages (144 KiB)
     case 6: return launch_cfg<2, 2, 4, 2, 4>(p, a->out_dtype, a->batch, stream);     // 128 x 64, 4 stages
-    case 7: return launch_cfg<4, 2, 4, 4, 2, 32, true>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32 (48 KiB)
     case 8: return launch_cfg<2, 2, 4, 4, 2, 32>(p, a->out_dtype, a->batch, stream); // 128 x 128 x 32 (32 KiB)
     case 9: return launch_cfg<2, 4, 8, 4, 2, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32 (64 KiB)
-    case 10: return launch_cfg<4, 2, 4, 4, 3, 32, true>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32, 3 stages (72 KiB)
     case 11: return launch_cfg<2, 4, 8, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32, 3 stages (96 KiB)
     case 13: return launch_cfg<4, 4, 4, 4, 3, 32>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 32, 16 waves of 64 x 64, 3 stages (96 KiB)
     case 14: return launch_cfg<4, 4, 4, 4, 2, 64>(p, a->out_dtype, a->batch, stream); // 256 x 256 x 64, 16 waves of 64 x 64, 2 stages (128 KiB)
@@ -1009,9 +1028,9 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     // late, so that the two blocks of a CU are out of phase — one's pipeline fill and store tail under the other's
     // K-loop — instead of running prologue, loop and epilogue in lockstep (fc1 / fc2 of stage 2: -5 %)
     case 32: p.skew_from = 256; p.skew_to = 512; p.skew_sleeps = 2;
-             return launch_cfg<4, 2, 4, 4, 3, 32, true>(p, a->out_dtype, a->batch, stream);
+             return launch_cfg<4, 2, 4, 4, 3, 32, kFold>(p, a->out_dtype, a->batch, stream);
     case 33: p.skew_from = 256; p.skew_to = 512; p.skew_sleeps = 3;
-             return launch_cfg<4, 2, 4, 4, 3, 32, true>(p, a->out_dtype, a->batch, stream);
+             return launch_cfg<4, 2, 4, 4, 3, 32, kFold>(p, a->out_dtype, a->batch, stream);
     case 12: if (p.out16 || p.ln_stats) return ODIC_EUNSUPPORTED;
              return launch_256sq(p, a->out_dtype, a->batch, stream);                 // 256 x 256 x 64, 4 phases per K-tile (128 KiB)
     // 16 + c: tile config c as a persistent, dynamically scheduled launch (needs args->workspace, batch == 1)
@@ -1034,4 +1053,8 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     case 27: return launch_persist<2, 4, 8, 4, 3, 32>(p, a->out_dtype, a->batch, stream);
     default: return ODIC_EINVAL;
   }
+#else
+    default: return ODIC_EINVAL;             // (tile configurations 3-6, 8, 9, 11-33: -DODIC_EXPERIMENTAL_GEMM builds only)
+  }
+#endif
 }

@@ -100,8 +100,11 @@ class SwinEngine:
         # Equally accurate (tools/fold_diag.py) and 44 launches fewer, but measured 1.5 % SLOWER end to end: the
         # LayerNorm kernels already run at 5 TB/s, and the producer's extra stores + the consumer's moment combine
         # cost the four products of a block 20 µs against the 16 µs of the two launches they replace.
+        # (the fold's GEMM forms are compiled only into -DODIC_EXPERIMENTAL_GEMM builds of the library)
         self.fold_ln = precision == "bf16" and os.environ.get("ODIC_FOLD_BACKBONE_LN", "0") == "1" and \
             all(g.stage_dim(s) % 64 == 0 for s in range(len(g.swin_depths)))
+        if self.fold_ln and b"experimental-gemm" not in _hip.load().odic_build_info():
+            raise RuntimeError("ODIC_FOLD_BACKBONE_LN=1 needs a library built with make EXTRA=-DODIC_EXPERIMENTAL_GEMM")
         if self.fold_ln:
             for s, (blocks, _) in enumerate(self.stages):
                 for b, w in enumerate(blocks):

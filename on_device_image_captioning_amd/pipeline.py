@@ -44,11 +44,14 @@ class CaptionPipeline:
     def __init__(self, model: CaptioningModel, batch: int, beam_size: int, max_seq_len: int, sos_idx: int,
                  eos_idx: int, use_graphs: bool = True, done_poll: int = 0, decode_lanes: int = 2,
                  streams=None, decode_group: int = 1, encode_lanes: int = 1, feat_len: int = 144,
-                 decode_cus: Optional[int] = None):
+                 decode_cus: Optional[int] = None, keep_scores: bool = False):
         """done_poll = 0: never look at the `done` flag (fixed work per batch — benchmark mode with
         weights that never emit EOS); n > 0: host checks every n steps and stops early.
         `model` is an End_ExpansionNet_v2 (inputs: images [B,3,H,W]) or a features-only ExpansionNet_v2
         (inputs: features [B, feat_len, F] + per-sample trailing pad counts, ExpansionNet_v2.py:50-70)."""
+        # keep_scores (verification runs): the best beam's per-token log-probs travel with its tokens, so that a
+        # pipelined search can be compared with the direct call bit for bit (collect_scored())
+        self.keep_scores = keep_scores
         self.model, self.B, self.k = model, batch, beam_size
         self.steps = max(1, max_seq_len - 1)
         self.T = self.steps + 1
@@ -119,6 +122,9 @@ class CaptionPipeline:
         self.out_len = [torch.zeros(self.NB, dtype=torch.int32, device=dv) for _ in range(self.RG)]
         self.host_tok = [torch.zeros(self.NB, self.T, dtype=torch.int32).pin_memory() for _ in range(self.RG)]
         self.host_len = [torch.zeros(self.NB, dtype=torch.int32).pin_memory() for _ in range(self.RG)]
+        if keep_scores:
+            self.host_lp = [torch.zeros(self.NB, self.T, dtype=torch.float32).pin_memory() for _ in range(self.RG)]
+            self._rows = torch.arange(self.NB, device=dv)
         self.ev_done = [torch.cuda.Event() for _ in range(self.RG)]
         self.ev_res_free = [torch.cuda.Event() for _ in range(self.RG)]   # device-side consumers are done with the slot
         for ev in self.ev_res_free:
@@ -327,6 +333,9 @@ class CaptionPipeline:
                                    self.out_len[gslot], self.NB, self.k, self.T, self.eos)
             self.host_tok[gslot].copy_(self.out_tok[gslot], non_blocking=True)
             self.host_len[gslot].copy_(self.out_len[gslot], non_blocking=True)
+            if self.keep_scores:                                    # (two ATen launches; verification runs only)
+                best = self.order[lane][:, 0].long()
+                self.host_lp[gslot].copy_(st.logprobs.view(self.NB, self.k, self.T)[self._rows, best], non_blocking=True)
             self.ev_done[gslot].record()
         self._gi += 1
         self._gfill = 0
@@ -369,6 +378,20 @@ class CaptionPipeline:
         self._collected += 1
         toks, lens = self.host_tok[gslot], self.host_len[gslot]
         return [toks[b, :int(lens[b])].tolist() for b in range(gpos * self.B, (gpos + 1) * self.B)]
+
+    def collect_scored(self) -> Tuple[List[List[int]], List[torch.Tensor]]:
+        """collect() plus the per-token log-probs (fp32, bit for bit what the search kept) of every caption; needs
+        keep_scores=True."""
+        if not self.keep_scores:
+            raise RuntimeError("construct the pipeline with keep_scores=True")
+        gi, gpos = self._oldest()
+        gslot = gi % self.RG
+        self.ev_done[gslot].synchronize()
+        self._where.pop(0)
+        self._collected += 1
+        toks, lens, lps = self.host_tok[gslot], self.host_len[gslot], self.host_lp[gslot]
+        rows = range(gpos * self.B, (gpos + 1) * self.B)
+        return ([toks[b, :int(lens[b])].tolist() for b in rows], [lps[b, :int(lens[b])].clone() for b in rows])
 
     def __call__(self, images: torch.Tensor, enc_num_pads: Optional[Sequence[int]] = None) -> List[List[int]]:
         self.submit(images, enc_num_pads)

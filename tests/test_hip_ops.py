@@ -29,6 +29,16 @@ def dev(t):
     return t.to("cuda")
 
 
+DEFAULT_BF16_TILE_CFGS = [0, 1, 2, 7, 10]        # what the default build of gemm_bf16.hip carries
+
+
+def _need_experimental_gemm():
+    """Tile configurations 3-6, 8, 9, 11-33 and the LayerNorm fold exist in -DODIC_EXPERIMENTAL_GEMM builds only."""
+    from on_device_image_captioning_amd import _hip
+    if b"experimental-gemm" not in _hip.load().odic_build_info():
+        pytest.skip("default build: experimental GEMM configurations are compiled out (make EXTRA=-DODIC_EXPERIMENTAL_GEMM)")
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
@@ -399,6 +409,7 @@ def test_dynexp_step_matches_full_recompute(ops):
 def test_gemm_bf16_256sq_phase_pipeline(ops):
     """Config 12 (256x256 tile, four phases per K-tile, counted LDS-DMA waits): ragged M/N, 2..24 K-tiles,
     every epilogue feature, and run-to-run identical results (a pipeline race shows up as flicker)."""
+    _need_experimental_gemm()
     for (M, N, K) in ((300, 328, 128), (517, 260, 384), (1024, 768, 768), (2304, 1536, 1536), (700, 3072, 256)):
         A, Wt = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=0.05).bfloat16()
         b, r = rnd(N, seed=3), rnd(M, N, seed=4)
@@ -423,6 +434,8 @@ def test_gemm_bf16_every_tile_config(ops, cfg):
     """Each tile / pipeline-depth / BK instantiation — one block per tile (0..11) and persistent with dynamic tile
     scheduling (16 + c) — against fp64 on ragged shapes (M, N not multiples of any tile) with every epilogue
     feature on."""
+    if cfg not in DEFAULT_BF16_TILE_CFGS:
+        _need_experimental_gemm()
     for (M, N, K) in ((300, 328, 192), (517, 260, 320)):
         A, Wt = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=0.05).bfloat16()
         b, r = rnd(N, seed=3), rnd(M, N, seed=4)
@@ -431,11 +444,25 @@ def test_gemm_bf16_every_tile_config(ops, cfg):
         assert_close(got, want, 2e-4, f"cfg{cfg} {M}x{N}x{K}")
 
 
+def test_gemm_bf16_default_build_rejects_compiled_out_configurations(ops):
+    from on_device_image_captioning_amd import _hip
+    if b"experimental-gemm" in _hip.load().odic_build_info():
+        pytest.skip("experimental build")
+    A, Wt = dev(rnd(256, 128, seed=1)).bfloat16(), dev(rnd(256, 128, seed=2)).bfloat16()
+    for cfg in (3, 12, 16, 33):
+        with pytest.raises(RuntimeError):
+            ops.gemm(A, Wt, tile_cfg=cfg)
+    with pytest.raises(RuntimeError):                  # the LayerNorm fold across two products is compiled out too
+        ops.gemm(A, Wt, out_dtype=torch.float32, out16=torch.empty(256, 256, dtype=torch.bfloat16, device="cuda"),
+                 stats_out=torch.empty(256, 8, 2, device="cuda"))
+
+
 @pytest.mark.parametrize("cfg", [16, 17, 23, 26])
 def test_gemm_bf16_persistent_many_tiles_per_block(ops, cfg):
     """Persistent launches where every block walks MANY tiles (more tiles than resident slots, tile stealing
     across XCD partitions at the end), all epilogue forms, the workspace re-armed launch after launch, and
     bit-identical results to the one-block-per-tile kernel of the same tile configuration (same MFMA order)."""
+    _need_experimental_gemm()
     for (M, N, K, act, odt) in ((9216, 3072, 768, 1, torch.bfloat16), (36864, 384, 384, 0, torch.float32),
                                 (20000, 1100, 128, 2, torch.float32)):
         A, Wt = rnd(M, K, seed=5).bfloat16(), rnd(N, K, seed=6, scale=0.05).bfloat16()
@@ -709,6 +736,7 @@ def test_gemm_bf16_layernorm_fold_producer_consumer(ops, cfg):
     moments; consumer: the next product normalises those rows in its epilogue.  Checked: the copy is the rounded
     output bit for bit, the moments are those of the bf16 values, and consumer == LayerNorm(copy)·Wᵀ + b in fp64
     (with the packed bf16 W·diag(gamma)), for rows with a large common offset too (the centred combination)."""
+    _need_experimental_gemm()
     M, C, N2 = 777, 384, 328
     A0, W0 = rnd(M, 256, seed=1).bfloat16(), rnd(C, 256, seed=2, scale=0.08).bfloat16()
     b0 = rnd(C, seed=3)
