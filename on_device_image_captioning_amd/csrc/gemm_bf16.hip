@@ -1008,6 +1008,18 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     case 2: return launch_cfg<2, 4, 8, 4, 2>(p, a->out_dtype, a->batch, stream);     // 256 x 256
     case 7: return launch_cfg<4, 2, 4, 4, 2, 32, kFold>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32 (48 KiB)
     case 10: return launch_cfg<4, 2, 4, 4, 3, 32, kFold>(p, a->out_dtype, a->batch, stream); // 256 x 128 x 32, 3 stages (72 KiB)
+    // 144- / 288-row tiles of 48 x 96 wave patches (MI = 3, NI = 6): the Swin-L token counts carry factors of 9
+    // (9216 = 32·288, 2304 = 16·144), so these tile grids are exact multiples of the 256 compute units where the
+    // power-of-two tiles leave a ragged last round (9216 x 3072: 512 tiles of 288 x 192 = two full rounds of one
+    // 12-wave block per CU, against 1.69 rounds of 256 x 128).  One block per CU; the fill traffic per MFMA is a
+    // quarter below the 256 x 128 tile's.
+    case 40: return launch_cfg<6, 2, 3, 6, 2, 64>(p, a->out_dtype, a->batch, stream);  // 288 x 192, 12 waves (120 KiB)
+    case 41: return launch_cfg<3, 3, 3, 6, 2, 64>(p, a->out_dtype, a->batch, stream);  // 144 x 288,  9 waves (108 KiB)
+    case 42: return launch_cfg<3, 2, 3, 6, 2, 64>(p, a->out_dtype, a->batch, stream);  // 144 x 192,  6 waves, 2 stages (84 KiB)
+    case 43: return launch_cfg<3, 2, 3, 6, 3, 64>(p, a->out_dtype, a->batch, stream);  // 144 x 192,  6 waves, 3 stages (126 KiB)
+    case 44: return launch_cfg<3, 1, 3, 6, 2, 64>(p, a->out_dtype, a->batch, stream);  // 144 x 96,   3 waves, 2 stages (60 KiB)
+    case 45: return launch_cfg<3, 3, 3, 6, 3, 32>(p, a->out_dtype, a->batch, stream);  // 144 x 288 x 32, 9 waves, 3 stages (81 KiB)
+    case 46: return launch_cfg<3, 1, 3, 6, 3, 64>(p, a->out_dtype, a->batch, stream);  // 144 x 96,   3 waves, 3 stages (90 KiB)
 #ifdef ODIC_EXPERIMENTAL_GEMM
     case 3: return launch_cfg<2, 2, 4, 2, 3>(p, a->out_dtype, a->batch, stream);     // 128 x 64, 3 stages
     case 4: return launch_cfg<2, 2, 4, 4, 3>(p, a->out_dtype, a->batch, stream);     // 128 x 128, 3 stages
