@@ -274,6 +274,12 @@ int odic_gemm_x3_launch(const odic_gemm_args* a, hipStream_t stream) {
     case 3: return launch<2, 2, 4, 4, 3>(p, a->out_dtype, a->batch, stream);      // 128 x 128, 3 stages (96 KiB)
     case 4: return launch<4, 2, 4, 4, 3>(p, a->out_dtype, a->batch, stream);      // 256 x 128, 3 stages (144 KiB)
     case 5: return launch<2, 2, 4, 2, 3>(p, a->out_dtype, a->batch, stream);      // 128 x 64,  3 stages (72 KiB)
+    // 48 x 96 wave patches in 144- / 288-row tiles (gemm_bf16.hip tile configs 40-42): exact multiples of 256 tiles on
+    // the 9216- / 2304-row products
+    case 6: return launch<6, 2, 3, 6, 2>(p, a->out_dtype, a->batch, stream);      // 288 x 192, 12 waves (120 KiB)
+    case 7: return launch<3, 3, 3, 6, 2>(p, a->out_dtype, a->batch, stream);      // 144 x 288,  9 waves (108 KiB)
+    case 8: return launch<3, 2, 3, 6, 2>(p, a->out_dtype, a->batch, stream);      // 144 x 192,  6 waves (84 KiB)
+    case 9: return launch<4, 2, 4, 4, 3>(p, a->out_dtype, a->batch, stream);      // 256 x 128, 3 stages (144 KiB) [as 4]
     default: return ODIC_EINVAL;
   }
 }

@@ -149,7 +149,7 @@ class autotune:
 
 
 _LOWP_CANDIDATES = (0, 1, 2, 3, 4)          # gemm_lowp.hip tile configurations (fp8 / fp16 operands)
-_X3_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_X3_TILE_CANDIDATES", "0,1,2,3").split(","))   # gemm_x3.hip
+_X3_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_X3_TILE_CANDIDATES", "0,1,2,5,6,7,8").split(","))   # gemm_x3.hip
 
 
 def _tune_gemm(args: "_hip.GemmArgs", key, out: torch.Tensor, candidates=None) -> int:

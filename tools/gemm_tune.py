@@ -22,6 +22,7 @@ ap.add_argument("--stages", default="0,1,2,3")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--inner", type=int, default=10)
 ap.add_argument("--vendor", action="store_true")
+ap.add_argument("--x3", action="store_true", help="split-fp16 operands (gemm_x3.hip tile configurations)")
 a = ap.parse_args()
 CFGS = [int(c) for c in a.cfgs.split(",")]
 shapes = []
@@ -38,10 +39,12 @@ print(f"{'shape':>26s} {'kind':>9s} | " + " | ".join(f"{n:>7s} us/TF" for n in n
 for M, N, K, kind in shapes:
     A = torch.randn(M, K, device="cuda").bfloat16()
     W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    if a.x3:
+        A, W = ops.cast_h2(A.float()), ops.cast_h2(W.float() * 4096.0)
     Wt = W.t()
     bias = torch.randn(N, device="cuda")
     res = torch.randn(M, N, device="cuda") if "res" in kind else None
-    odt = torch.float32 if ("res" in kind or kind == "merge") else torch.bfloat16
+    odt = torch.float32 if ("res" in kind or kind == "merge") else (ops.H2_DTYPE if a.x3 else torch.bfloat16)
     out = torch.empty(M, N, device="cuda", dtype=odt)
     out16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     act = ops.ACT_GELU if "gelu" in kind else ops.ACT_NONE
@@ -54,7 +57,7 @@ for M, N, K, kind in shapes:
             fns[f"cfg{cfg}"] = f
         except RuntimeError:
             pass
-    if a.vendor:
+    if a.vendor and not a.x3:
         fns["vendor"] = lambda: torch.mm(A, Wt, out=out16)
     times = {n: [] for n in fns}
     for n, f in fns.items():
