@@ -45,7 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}     # MI355X_MICROARCH.md
+PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_fp8_tflops": 5000.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}     # MI355X_MICROARCH.md
 SOS, EOS = 79, 77
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic_{workload}.json")     # collected per workload
 
@@ -296,10 +296,12 @@ def roofline_entry(name, d, workload=None):
     sec = d["ms"] * 1e-3
     mfma = name.startswith("gemm") or name.startswith("swin_attention_block")
     if mfma:
-        # (the non-scaled fp8 MFMA issues at the bf16 rate, MI355X_MICROARCH.md § Matrix cores: priced against 2.5 PF)
-        # gemm_x3 (split fp16): three fp16 MFMAs per algorithmic product → priced against a third of the fp16 peak
+        # gemm_fp8: the block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales) carries the 5 PFLOP/s fp8 rate
+        # (MI355X_MICROARCH.md § Matrix cores) — priced against it; gemm_x3 (split fp16): three fp16 MFMAs per
+        # algorithmic product → priced against a third of the fp16 peak
         peak = PEAK["mfma_f32_tflops"] if name == "gemm_f32" else \
-            round(PEAK["mfma_bf16_tflops"] / 3.0, 1) if name == "gemm_x3" else PEAK["mfma_bf16_tflops"]
+            round(PEAK["mfma_bf16_tflops"] / 3.0, 1) if name == "gemm_x3" else \
+            PEAK["mfma_fp8_tflops"] if name == "gemm_fp8" else PEAK["mfma_bf16_tflops"]
         ach = d["flops"] / sec / 1e12
         e = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
              "frac": round(ach / peak, 4), "algorithmic_flops_per_step": d["flops"]}

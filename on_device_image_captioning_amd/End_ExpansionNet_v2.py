@@ -79,7 +79,8 @@ class End_ExpansionNet_v2(CaptioningModel):
         if self._eng_cache is None:
             dv = self._device()
             sd = self.state_dict()
-            self._eng_cache = (_engine.SwinEngine(sd, self.geometry, dv, self.precision),
+            self._eng_cache = (_engine.SwinEngine(sd, self.geometry, dv, self.precision,
+                                                  calibration_images=self.calibration_images),
                                _engine.CaptionerEngine(sd, self.geometry, dv, self.encoder_precision or ("bf16" if self.precision == "fp8" else self.precision)))
         return self._eng_cache
 

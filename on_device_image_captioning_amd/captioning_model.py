@@ -36,6 +36,7 @@ class CaptioningModel(nn.Module):
         self._eng_cache = None
         self.precision = "fp32"
         self.encoder_precision = None       # None = follow `precision`
+        self.calibration_images = None      # fp8 mode: images the static activation scales are calibrated on
         self.sampling_seed = 0              # Philox key of the device-side draws ('sample' / 'sampling' modes)
         self._sampling_calls = 0
         self._draw_log = None               # list → every sampled-beam-search draw is appended (tests)
@@ -45,7 +46,8 @@ class CaptioningModel(nn.Module):
         if self.rank is None:
             raise NotImplementedError("Subclass must assign the rank integer according to the GPU group")
 
-    def set_precision(self, precision: str, encoder_precision: Optional[str] = None) -> "CaptioningModel":
+    def set_precision(self, precision: str, encoder_precision: Optional[str] = None,
+                      calibration_images: Optional[torch.Tensor] = None) -> "CaptioningModel":
         """'fp32' (default; exact-fp32 MFMA, parity mode), 'bf16' (backbone GEMMs + window attention in bf16 with
         fp32 accumulation and an fp32 residual stream; expansion-encoder products in bf16 too unless
         `encoder_precision='fp32'`) or 'fp8' (BASELINE.json configs[4]: Swin-block GEMMs qkv / fc1 / fc2 on the fp8
@@ -53,17 +55,38 @@ class CaptioningModel(nn.Module):
         'x3' — the near-exact fast mode: every backbone / encoder contraction on split-fp16 operands (hi + lo pairs,
         22 significand bits, three fp16 MFMAs per product with fp32 accumulation; 'bf16x3' is accepted as an alias
         for the name the technique usually goes by), fp32 residual streams, exact-erf GELU — the mode that reproduces
-        the fp32 (= reference) captions at several times the exact-fp32 MFMA rate.  The decoder is always fp32."""
+        the fp32 (= reference) captions at several times the exact-fp32 MFMA rate.  The decoder is always fp32.
+        `calibration_images` (fp8 only; fp32 [n,3,H,W], preprocessed like the inputs): the images the static per-tensor
+        activation scales are measured on (amax x 1.25 → the e4m3 maximum).  Default: two synthetic noise images —
+        fine for synthetic benchmarks, NOT for real photographs, whose LayerNorm / GELU ranges differ; the fp8 casts
+        saturate silently at ±448, so calibrate on a sample of the deployment distribution and check
+        `fp8_saturation_report(images)` on held-out images."""
         if precision == "bf16x3":
             precision = "x3"
         if encoder_precision == "bf16x3":
             encoder_precision = "x3"
         if precision not in ("fp32", "bf16", "fp8", "x3") or (encoder_precision or "bf16") not in ("fp32", "bf16", "x3"):
             raise ValueError("precision must be 'fp32', 'bf16', 'fp8' or 'x3' (encoder_precision 'fp32', 'bf16' or 'x3')")
-        if (precision, encoder_precision) != (self.precision, self.encoder_precision):
+        if calibration_images is not None and precision != "fp8":
+            raise ValueError("calibration_images only applies to precision='fp8'")
+        same_cal = (calibration_images is None and self.calibration_images is None) or \
+            (calibration_images is not None and self.calibration_images is not None and
+             calibration_images.shape == self.calibration_images.shape and
+             bool(torch.equal(calibration_images.detach().cpu(), self.calibration_images)))
+        if (precision, encoder_precision) != (self.precision, self.encoder_precision) or not same_cal:
             self.precision, self.encoder_precision = precision, encoder_precision
+            self.calibration_images = None if calibration_images is None else calibration_images.detach().float().cpu().clone()
             self._eng_cache = None
         return self
+
+    def fp8_saturation_report(self, images: torch.Tensor) -> dict:
+        """fp8 mode: how the activation ranges of `images` compare with the calibrated scales — per quantised tensor
+        (LayerNorm outputs and GELU hidden of every Swin block) the ratio observed amax / representable range; a ratio
+        above 1 means the static cast clips there (End_ExpansionNet_v2 only)."""
+        if self.precision != "fp8":
+            raise RuntimeError("fp8_saturation_report needs set_precision('fp8')")
+        swin = self._engines()[0]
+        return swin.fp8_saturation(images.to(swin.device, torch.float32))
 
     def _next_sampling_seed(self) -> int:
         """A fresh Philox key per sampling call (so repeated calls differ), reproducible from `sampling_seed`."""

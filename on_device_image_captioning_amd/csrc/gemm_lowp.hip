@@ -50,8 +50,16 @@ __device__ __forceinline__ int wperm(int r) {
 __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) { return f32x4_to_fp8(a, b, c, d); }
 
 // EB = bytes per input element (1: fp8, 2: fp16).  OutT ∈ {float, f16_t, fp8_raw}.
-template <int NWM, int NWN, int MI, int NI, int NSTAGE, int ROWB, int EB, typename OutT>
+// MX (fp8, 128-byte rows only): the block-scaled instruction v_mfma_scale_f32_16x16x128_f8f6f4 with e4m3 operands and unit
+// E8M0 scales (127 = 2^0): ONE MFMA per 16x16 tile and 128-deep K-tile at twice the fp8 FLOPs per clock of the four
+// non-scaled v_mfma_f32_16x16x32_fp8_fp8 it replaces (MI355X_MICROARCH.md § Matrix cores: the 5 PFLOP/s fp8 rate exists
+// only on the scaled form).  A lane's operand is 32 consecutive K-bytes of its row = LDS chunks 2·fq, 2·fq + 1; both
+// operands use the same assignment, and a dot product does not care which K the hardware pairs first.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int ROWB, int EB, typename OutT, bool MX = false>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_lowp_nt_kernel(Params p) {
+  static_assert(!MX || (EB == 1 && ROWB == 128), "the block-scaled form is fp8 on 128-byte K-tiles");
   constexpr int NW = NWM * NWN;
   constexpr int BK = ROWB / EB;                // K elements per K-tile
   constexpr int RPI = 1024 / ROWB;             // rows per 1-KiB DMA instruction
@@ -130,6 +138,27 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_lowp_nt_kernel(Params p) 
     const int cur = kt % NSTAGE;
     const char* la = lds + cur * STAGE + (wm * MI * 16 + frow) * ROWB;
     const char* lw = lds + cur * STAGE + A_BYTES + (wn * NI * 16 + frow) * ROWB;
+    if constexpr (MX) {
+      const int c0 = swz<ROWB>(2 * fq, frow) << 4, c1 = swz<ROWB>(2 * fq + 1, frow) << 4;
+      i32x8_t af[MI], wf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const i32x4_t lo = *(const i32x4_t*)(la + mi * 16 * ROWB + c0), hi = *(const i32x4_t*)(la + mi * 16 * ROWB + c1);
+        af[mi] = i32x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const i32x4_t lo = *(const i32x4_t*)(lw + ni * 16 * ROWB + c0), hi = *(const i32x4_t*)(lw + ni * 16 * ROWB + c1);
+        wf[ni] = i32x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], af[mi], acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                         0x7f7f7f7f);
+      continue;
+    }
 #pragma unroll
     for (int kk = 0; kk < ROWB / 64; ++kk) {     // 64-byte slabs of a row: chunk kk*4 + fq
       const int chunk = swz<ROWB>(kk * 4 + fq, frow) << 4;
@@ -236,7 +265,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_lowp_nt_kernel(Params p) 
   }
 }
 
-template <int NWM, int NWN, int MI, int NI, int NSTAGE, int ROWB, int EB>
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int ROWB, int EB, bool MX = false>
 int launch(Params& p, int out_dtype, hipStream_t stream) {
   constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
   constexpr int SHMEM = NSTAGE * (BM + BN) * ROWB;
@@ -254,9 +283,9 @@ int launch(Params& p, int out_dtype, hipStream_t stream) {
       if (r > max_rect) max_rect = r;
     }
   dim3 grid(8 * max_rect), block(64 * NWM * NWN);
-  auto k32 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, ROWB, EB, float>;
-  auto k16 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, ROWB, EB, f16_t>;
-  auto k8 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, ROWB, EB, fp8_raw>;
+  auto k32 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, ROWB, EB, float, MX>;
+  auto k16 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, ROWB, EB, f16_t, MX>;
+  auto k8 = gemm_lowp_nt_kernel<NWM, NWN, MI, NI, NSTAGE, ROWB, EB, fp8_raw, MX>;
   if (SHMEM > 64 * 1024) {
     static bool done = false;       // code-object attribute; idempotent
     if (!done) {
@@ -283,6 +312,20 @@ int dispatch(Params& p, const odic_gemm_args* a, hipStream_t stream) {
     };
     const double c0 = rounds(128, 64, 768) * 1.0, c1 = rounds(128, 128, 512) * 1.38, c2 = rounds(256, 128, 512) * 2.2;
     cfg = (c0 <= c1 && c0 <= c2) ? 0 : (c1 <= c2 ? 1 : 2);
+  }
+  if constexpr (EB == 1) {
+    // tile configurations 5..9 = 0..4 on the block-scaled fp8 MFMA (K % 128 == 0); the built-in choice prefers them
+    if (a->tile_cfg < 0 && a->K % 128 == 0) cfg += 5;
+    if (cfg >= 5 && cfg <= 9) {
+      if (a->K % 128 != 0) return ODIC_EINVAL;
+      switch (cfg) {
+        case 5: return launch<2, 2, 4, 2, 2, 128, 1, true>(p, a->out_dtype, stream);    // 128 x 64,  2 stages (48 KiB)
+        case 6: return launch<2, 2, 4, 4, 2, 128, 1, true>(p, a->out_dtype, stream);    // 128 x 128, 2 stages (64 KiB)
+        case 7: return launch<4, 2, 4, 4, 2, 128, 1, true>(p, a->out_dtype, stream);    // 256 x 128, 2 stages (96 KiB)
+        case 8: return launch<2, 2, 4, 4, 3, 128, 1, true>(p, a->out_dtype, stream);    // 128 x 128, 3 stages (96 KiB)
+        default: return launch<4, 2, 4, 4, 3, 128, 1, true>(p, a->out_dtype, stream);   // 256 x 128, 3 stages (144 KiB)
+      }
+    }
   }
   if ((a->K * EB) % 128 == 0) {
     switch (cfg) {

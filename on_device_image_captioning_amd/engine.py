@@ -131,6 +131,7 @@ class SwinEngine:
         self.forward(img.to(dv, torch.float32), _amax=amax)                 # bf16 pass recording the operand ranges
         P = "swin_transf"
         margin = 1.25
+        self.fp8_range = {k: margin * v for k, v in amax.items()}           # what each static scale can represent
         for s, (blocks, _) in enumerate(self.stages):
             for b, w in enumerate(blocks):
                 p = f"{P}.layers.{s}.blocks.{b}"
@@ -149,6 +150,18 @@ class SwinEngine:
                     fc2_w8=q_fc2, fc2_cs=(sw_fc2 * sh).contiguous(),
                     proj_w16=f32(p + ".attn.proj.weight").to(torch.float16).contiguous()))
         self.fp8_ready = True
+
+    def fp8_saturation(self, img: torch.Tensor) -> dict:
+        """Observed operand ranges of `img` (one bf16 pass) against the calibrated fp8 ranges: the tensors whose
+        amax exceeds what the static scale represents are cast with clipping at ±448."""
+        if not self.fp8_ready:
+            raise RuntimeError("not an fp8 engine")
+        seen = {}
+        self.forward(img, _amax=seen)
+        ratios = {k: seen[k] / self.fp8_range[k] for k in seen}
+        over = {f"s{k[0]}b{k[1]}.{k[2]}": round(v, 3) for k, v in ratios.items() if v > 1.0}
+        return {"tensors": len(ratios), "clipping_tensors": len(over), "worst_ratio": round(max(ratios.values()), 3),
+                "median_ratio": round(sorted(ratios.values())[len(ratios) // 2], 3), "clipping": over}
 
     def forward(self, img: torch.Tensor, taps: Optional[dict] = None, out_dtype=torch.float32,
                 _amax: Optional[dict] = None) -> torch.Tensor:

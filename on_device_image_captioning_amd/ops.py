@@ -148,7 +148,8 @@ class autotune:
         return False
 
 
-_LOWP_CANDIDATES = (0, 1, 2, 3, 4)          # gemm_lowp.hip tile configurations (fp8 / fp16 operands)
+_LOWP_CANDIDATES = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)   # gemm_lowp.hip tile configurations (fp8 / fp16 operands; 5-9: the
+                                                    # block-scaled fp8 MFMA, rejected for fp16 / K % 128 != 0 and then skipped)
 _X3_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_X3_TILE_CANDIDATES", "0,1,2,5,6,7,8").split(","))   # gemm_x3.hip
 
 

@@ -671,18 +671,24 @@ def _to_fp8(t):
     return t.clamp(-448, 448).to(torch.float8_e4m3fn)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_gemm_fp8_identity_and_random(ops, cfg):
     """odic_gemm with fp8 (OCP e4m3) operands: exact on integer data with A = I and an ASYMMETRIC W (layout check of
     the 16x16x32 fp8 MFMA fragments, the two-MFMAs-per-16-byte-read K assignment, the permuted W rows), then random
     data against fp64 of the same fp8 values with every epilogue feature (per-column scale, bias, GELU, out_scale,
-    residual) and the three output types."""
+    residual) and the three output types.  Tile configurations 5..9 are 0..4 on the BLOCK-SCALED fp8 MFMA
+    (v_mfma_scale_f32_16x16x128_f8f6f4, unit E8M0 scales — the instruction that carries gfx950's 5 PFLOP/s fp8 rate);
+    they need K % 128 == 0 and are what the built-in choice (-1) takes when K allows."""
     n = 256
     eye = _to_fp8(torch.eye(n))
     Wt = _to_fp8(((torch.arange(n)[:, None] * 3 + torch.arange(n)[None, :] * 5) % 17 - 8).float())
     got = ops.gemm(dev(eye), dev(Wt), out_dtype=torch.float32, tile_cfg=cfg)
     assert torch.equal(got.cpu(), Wt.float().T.contiguous())
     for (M, N, K) in ((300, 328, 256), (517, 264, 384), (2304, 768, 1024), (1000, 576, 192)):   # K = 192: 64-byte rows
+        if cfg >= 5 and K % 128:
+            with pytest.raises(RuntimeError):
+                ops.gemm(dev(_to_fp8(rnd(M, K, seed=1))), dev(_to_fp8(rnd(N, K, seed=2))), out_dtype=torch.float32, tile_cfg=cfg)
+            continue
         A, Wq = _to_fp8(rnd(M, K, seed=1, scale=2.0)), _to_fp8(rnd(N, K, seed=2, scale=3.0))
         cs, b, r = rnd(N, seed=3).abs() * 0.01 + 0.005, rnd(N, seed=4), rnd(M, N, seed=5)
         lin = (A.double() @ Wq.double().T) * cs.double() + b.double()
