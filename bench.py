@@ -47,7 +47,7 @@ if ROOT not in sys.path:
 
 PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_fp8_tflops": 5000.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}     # MI355X_MICROARCH.md
 SOS, EOS = 79, 77
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic_{workload}.json")     # collected per workload
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic_{workload}_{precision}.json")     # collected per workload and mode
 
 WORKLOADS = {
     "e2e16": dict(
@@ -276,14 +276,14 @@ _PMC = None
 _PMC_PATH = None
 
 
-def pmc_traffic(name, workload=None):
+def pmc_traffic(name, workload=None, precision="default"):
     """HBM bytes per launch of a kernel family from the committed PMC passes of THIS workload (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs of this very command; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
     prescribes; tools/collect_profiles.sh, tools/pmc_traffic_json.py); None where no pass was collected.
     bench.py cannot read hardware counters itself."""
     global _PMC, _PMC_PATH
     if _PMC is None:
-        _PMC_PATH = PMC_FILE.format(workload=workload or "e2e16")
+        _PMC_PATH = PMC_FILE.format(workload=workload or "e2e16", precision=precision)
         try:
             with open(_PMC_PATH) as f:
                 _PMC = json.load(f)
@@ -292,7 +292,7 @@ def pmc_traffic(name, workload=None):
     return _PMC.get(name, {}).get("hbm_bytes_per_launch")
 
 
-def roofline_entry(name, d, workload=None):
+def roofline_entry(name, d, workload=None, precision="default"):
     sec = d["ms"] * 1e-3
     mfma = name.startswith("gemm") or name.startswith("swin_attention_block")
     if mfma:
@@ -309,7 +309,7 @@ def roofline_entry(name, d, workload=None):
         ach = d["bytes"] / sec / 1e9
         e = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK["hbm_gbs"], "unit": "GB/s",
              "frac": round(ach / PEAK["hbm_gbs"], 4), "algorithmic_bytes_per_step": d["bytes"]}
-    e.update({"traffic": pmc_traffic(name, workload), "launches": d["launches"],
+    e.update({"traffic": pmc_traffic(name, workload, precision), "launches": d["launches"],
               "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
               "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"])})
     return e
@@ -503,12 +503,13 @@ def main():
             fam = roofline_pass(pipe, images)
             derived = {n: fam.pop(n) for n in list(fam) if n.startswith("swin_attention_block")}
             total_ms = sum(d["ms"] for d in fam.values())
-            entries = sorted((roofline_entry(n, d, a.workload) for n, d in fam.items()), key=lambda e: -fam[e["kernel"]]["ms"])
+            pkey = "default" if a.precision == WORKLOADS[a.workload]["precision"] else a.precision
+            entries = sorted((roofline_entry(n, d, a.workload, pkey) for n, d in fam.items()), key=lambda e: -fam[e["kernel"]]["ms"])
             for e in entries:
                 e["time_share"] = round(fam[e["kernel"]]["ms"] / total_ms, 4)
             out["roofline"] = entries[0]
             for n, d in derived.items():             # three launches per Swin block, already counted above
-                e = roofline_entry(n, d, a.workload)
+                e = roofline_entry(n, d, a.workload, pkey)
                 e["time_share"] = round(d["ms"] / total_ms, 4)
                 e["note"] = ("fused-form accounting of SURVEY 8(d): algorithmic FLOPs of qkv Linear + attention core + "
                              "proj Linear per Swin block over the summed durations of those three launches")

@@ -94,6 +94,7 @@ class SwinEngine:
                 down = dict(nw=f32(p + ".norm.weight"), nb=f32(p + ".norm.bias"), red_w=red_w, red_a=red_a)
             self.stages.append((blocks, down))
         self.fn_w, self.fn_b = f32(f"{P}.norm.weight"), f32(f"{P}.norm.bias")
+        self.stage_chunks = [int(v) for v in os.environ.get("ODIC_SWIN_CHUNKS", "1").split(",")]
         # Optional (ODIC_FOLD_BACKBONE_LN=1, bf16 mode): norm2 and the norm1 of every block but a stage's first folded
         # across the products around them (ops.gemm producer / consumer form): the proj / fc2 product leaves a bf16
         # copy of the residual stream plus row-group moments, the fc1 / next qkv product normalises in its epilogue.
@@ -178,7 +179,16 @@ class SwinEngine:
         for s, (blocks, down) in enumerate(self.stages):
             res, C_, heads, ws = g.stage_res(s), g.stage_dim(s), g.swin_num_heads[s], g.stage_window(s)
             x = x.view(B * res * res, C_)
-            for bi, w in enumerate(blocks):
+            # image chunks (stage_chunks): a stage's blocks run over B/n images at a time, so that what one launch
+            # writes (qkv, the MLP hidden, the residual stream) is still in the 256 MB Infinity Cache when the
+            # next launch reads it — the stage-0/1 launches are HBM-bound
+            n_ch = self.stage_chunks[s] if s < len(self.stage_chunks) else 1
+            if taps is not None or _amax is not None or self.fold_ln or n_ch < 1 or B % n_ch:
+                n_ch = 1
+            x_all, B_all = x, B
+            B = B_all // n_ch
+            for ci, bi, w in ((ci, bi, w) for ci in range(n_ch) for bi, w in enumerate(blocks)):
+                x = x_all[ci * B * res * res:(ci + 1) * B * res * res]
                 if fp8:
                     # LN → fp8 | qkv: fp8 MFMA → fp16 | attention fp16 | proj: fp16 MFMA + residual
                     xn = ops.layernorm(x, w["n1w8"], w["n1b8"], out_dtype=ops.FP8_DTYPE)
@@ -225,6 +235,7 @@ class SwinEngine:
                     ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x, alpha=w["fc2_a"])
                 if taps is not None:
                     taps[f"s{s}b{bi}"] = x.view(B, res * res, C_).clone()
+            x, B = x_all, B_all
             if down is not None:
                 xm = ops.patch_merge_layernorm(x, down["nw"], down["nb"], B, res, C_, out_dtype=cdt)
                 x = ops.gemm(xm.view(-1, 4 * C_), down["red_w"], out_dtype=torch.float32, alpha=down["red_a"])

@@ -977,3 +977,19 @@ def test_fp8_b64_pipeline_equals_direct_call():
     want = [c for b in batches + batches[::-1] for c in _direct(m, b)]
     build_model("FULL", "xavier", "fp32")
     assert got == want and len(got) == 256
+
+
+@pytest.mark.parametrize("precision", ["bf16", "x3", "fp32"])
+def test_image_chunked_stages_give_the_same_features_bit_for_bit(precision):
+    """`SwinEngine.stage_chunks` (ODIC_SWIN_CHUNKS) runs a stage's blocks over B/n images at a time: every kernel is
+    per-row / per-window, so the features must not change by a bit — whatever tile the tuner picks for the smaller M."""
+    from on_device_image_captioning_amd.engine import SwinEngine
+    g = W.FULL
+    eng = SwinEngine(cached_state_dict("FULL", "xavier"), g, torch.device(DEV), precision)
+    img = W.synth_images(4, g, seed=77).to(DEV)
+    eng.stage_chunks = [1]
+    ref = eng.forward(img).clone()
+    for chunks in ([2, 2], [4, 2, 2], [4, 4, 4, 4], [3, 1]):        # 3 does not divide 4: that stage stays whole
+        eng.stage_chunks = chunks
+        out = eng.forward(img)
+        assert torch.equal(out, ref), (precision, chunks, float((out - ref).abs().max()))

@@ -8,7 +8,8 @@ import re
 import sys
 from collections import defaultdict
 
-FAMILIES = {"gemm_bf16": r"gemm_bf16_", "gemm_f32": r"gemm_f32_", "gemm_fp8": r"gemm_lowp_nt_kernel<(\d+, ){6}1,",
+FAMILIES = {"gemm_bf16": r"gemm_bf16_", "gemm_x3": r"gemm_x3_nt_kernel", "window_attention_x3": r"window_attention_h2_kernel",
+            "gemm_f32": r"gemm_f32_", "gemm_fp8": r"gemm_lowp_nt_kernel<(\d+, ){6}1,",
             "gemm_f16": r"gemm_lowp_nt_kernel<(\d+, ){6}2,", "layernorm": r"\blayernorm_kernel",
             "window_attention_bf16": r"window_attention_bf16", "patch_embed": r"patch_embed_kernel",
             "patch_merge_layernorm": r"layernorm_kernel<\d+, true", "cross_attn_step": r"cross_attn_step_kernel",
