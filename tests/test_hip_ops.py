@@ -444,6 +444,72 @@ def test_gemm_bf16_every_tile_config(ops, cfg):
         assert_close(got, want, 2e-4, f"cfg{cfg} {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("cfg,K,bm,bnc", [(50, 192, 256, 64), (52, 192, 128, 64), (51, 384, 128, 32), (53, 384, 128, 64)])
+def test_gemm_bf16_a_resident_streaming_kernels(ops, cfg, K, bm, bnc):
+    """tile_cfg 50-52 (gemm_bf16_apanel_kernel: A rows in registers over the whole K, W chunks streamed through LDS, counted
+    store waits) — against fp64 AND bit-for-bit against the tiled kernel (same MFMA, same K order), over every epilogue
+    the Swin stage-0/1 products use, panel / chunk counts that exercise every column-range split (1 chunk per block, uneven
+    ranges, several panels per XCD), and a strided output; shapes that are not whole tiles are refused."""
+    g = torch.Generator().manual_seed(cfg)
+    for M, N in ((bm * 3, bnc * 5), (bm * 17, bnc * 12), (bm * 9, bnc * 1)):
+        A = dev(torch.randn(M, K, generator=g)).bfloat16()
+        Wt = dev(torch.randn(N, K, generator=g) * 0.05).bfloat16()
+        b, r = dev(torch.randn(N, generator=g)), dev(torch.randn(M, N, generator=g))
+        lin = A.double() @ Wt.double().T
+        for name, kw, want in (
+                ("plain", dict(out_dtype=torch.bfloat16), lin),
+                ("bias", dict(bias=b, out_dtype=torch.bfloat16), lin + b.double()),
+                ("bias+gelu", dict(bias=b, act=ops.ACT_GELU, out_dtype=torch.bfloat16),
+                 torch.nn.functional.gelu(lin + b.double())),
+                ("alpha+bias f32", dict(bias=b, alpha=0.25, out_dtype=torch.float32), 0.25 * lin + b.double()),
+                ("bias+residual f32", dict(bias=b, residual=r, out_dtype=torch.float32), lin + b.double() + r.double())):
+            if "residual" in kw and cfg == 50:
+                with pytest.raises(RuntimeError):          # the 64-row-per-wave form has no residual instantiation
+                    ops.gemm(A, Wt, tile_cfg=cfg, **kw)
+                continue
+            got = ops.gemm(A, Wt, tile_cfg=cfg, **kw)
+            ref = ops.gemm(A, Wt, tile_cfg=0, **kw)
+            assert_close(got, want, 6e-3 if kw["out_dtype"] == torch.bfloat16 else 3e-4, f"cfg{cfg} {name} {M}x{N}x{K}")
+            assert torch.equal(got, ref), (cfg, name, M, N, float((got.float() - ref.float()).abs().max()))
+    # residual aliasing the output (x += proj(...)) and a strided fp32 output, as engine.SwinEngine calls it
+    if cfg != 50:
+        M, N = bm * 4, bnc * 6
+        A = dev(torch.randn(M, K, generator=g)).bfloat16()
+        Wt = dev(torch.randn(N, K, generator=g) * 0.05).bfloat16()
+        wide = dev(torch.randn(M, 2 * N, generator=g))
+        x = wide[:, N:]
+        want = (A.double() @ Wt.double().T).float() + x.clone()
+        ops.gemm(A, Wt, residual=x, out=x, M=M, N=N, K=K, lda=K, ldw=K, ldr=2 * N, ldc=2 * N, tile_cfg=cfg)
+        assert_close(x, want, 3e-4, f"cfg{cfg} in-place residual")
+    for M, N, Kx in ((bm * 2 + 16, bnc * 4, K), (bm * 2, bnc * 4 + 8, K), (bm * 2, bnc * 4, K + 64)):
+        with pytest.raises(RuntimeError):
+            ops.gemm(dev(torch.zeros(M, Kx)).bfloat16(), dev(torch.zeros(N, Kx)).bfloat16(), tile_cfg=cfg)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 7, 10])
+def test_gemm_bf16_whole_line_store_epilogue(ops, cfg):
+    """bf16 outputs with N % 64 == 0 leave the tiled kernel through the lane-exchange epilogue (two column groups
+    swapped between lanes frow and frow ^ 8, 8 rows x 128 bytes per store): ragged M (rows 8-15 of the last 16 absent,
+    a lone row), every epilogue feature, a strided output — against fp64 and bit-for-bit against tile_cfg 0 (NI = 2:
+    the plain 16-byte stores)."""
+    g = torch.Generator().manual_seed(100 + cfg)
+    for M, N, K in ((300, 320, 192), (517, 256, 320), (1, 64, 64), (264, 192, 128)):
+        A = dev(torch.randn(M, K, generator=g)).bfloat16()
+        Wt = dev(torch.randn(N, K, generator=g) * 0.05).bfloat16()
+        b, r = dev(torch.randn(N, generator=g)), dev(torch.randn(M, N, generator=g))
+        lin = A.double() @ Wt.double().T
+        for name, kw, want in (("plain", {}, lin), ("bias+gelu", dict(bias=b, act=ops.ACT_GELU), torch.nn.functional.gelu(lin + b.double())),
+                               ("alpha+bias+res", dict(bias=b, residual=r, alpha=0.5), 0.5 * lin + b.double() + r.double())):
+            got = ops.gemm(A, Wt, out_dtype=torch.bfloat16, tile_cfg=cfg, **kw)
+            ref = ops.gemm(A, Wt, out_dtype=torch.bfloat16, tile_cfg=0, **kw)
+            assert_close(got, want, 6e-3, f"cfg{cfg} {name} {M}x{N}x{K}")
+            assert torch.equal(got, ref), (cfg, name, M, N, K)
+        wide = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(A, Wt, b, out=wide, M=M, N=N, K=K, lda=K, ldw=K, ldc=N + 64, tile_cfg=cfg)
+        assert_close(wide[:, :N], lin + b.double(), 6e-3, f"cfg{cfg} strided {M}x{N}x{K}")
+        assert torch.all(wide[:, N:] == 7.0)
+
+
 def test_gemm_bf16_default_build_rejects_compiled_out_configurations(ops):
     from on_device_image_captioning_amd import _hip
     if b"experimental-gemm" in _hip.load().odic_build_info():
