@@ -27,6 +27,7 @@
 #include "odic_common.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -279,6 +280,107 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && MI * NI == 32) ?
           if (ra + 8 < p.M) *(i32x4_t*)(dst + 8 * p.ldc) = lo ? recv : own[1];
         }
       }
+      return;
+    }
+  }
+  if constexpr (LNF == 0 && !(sizeof(OutT) == 2 && NI % 4 == 0)) {   // (bf16 with NI % 4 == 0: whole-line path above, or the plain loop below)
+    // The general vector path.  vmcnt retires in order and counts stores, so ANY load between two groups of stores
+    // waits for every store before it: a bias or residual load per column group turned the epilogue into a chain of
+    // memory round trips (9 per 144 x 192 tile; the "+16-20 us for the fp32 residual form" of DESIGN.md §4.1).  Here
+    // every bias value is requested before the first store, and the residual rows of column group g + 1 are requested
+    // BEFORE the stores of group g (they are then older than those stores, and waiting for them waits for nothing else).
+    if (ld_ok && (p.N & 7) == 0) {
+      constexpr int NG = NI / 2;
+      // residual prefetch depth: 2 = pipelined as above (4- and 6-wave blocks: the registers are there), 1 = a group's
+      // rows requested together (12-wave blocks), 0 = row by row (8-wave blocks: 32 more registers would cost them
+      // their second resident block)
+      constexpr int RD = sizeof(OutT) == 4 ? (NW <= 6 ? 2 : (NW >= 12 ? 1 : 0)) : 0;
+      const int cw = n0 + wn * NI * 16 + fq * 8;
+      f32x4_t bc[NG][2];
+      float brow[MI];
+#pragma unroll
+      for (int nq = 0; nq < NG; ++nq) bc[nq][0] = bc[nq][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) brow[mi] = 0.f;
+      if (bias && !p.bias_axis) {                       // (uniform branches around whole groups of loads)
+        if ((reinterpret_cast<uintptr_t>(bias) & 15) == 0) {
+#pragma unroll
+          for (int nq = 0; nq < NG; ++nq) {
+            const f32x4_t* bp = (const f32x4_t*)(bias + min(cw + nq * 32, p.N - 8));
+            bc[nq][0] = bp[0]; bc[nq][1] = bp[1];
+          }
+        } else {
+#pragma unroll
+          for (int nq = 0; nq < NG; ++nq) {
+            const float* bp = bias + min(cw + nq * 32, p.N - 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bc[nq][0][e] = bp[e]; bc[nq][1][e] = bp[4 + e]; }
+          }
+        }
+      } else if (bias) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) brow[mi] = bias[min(m0 + (wm * MI + mi) * 16 + frow, p.M - 1)];
+      }
+      // (two copies of the store loop, with and without a residual, so that the residual loads are unconditional:
+      //  a load under a lane-dependent branch makes hipcc's wait insertion fall back to vmcnt(0))
+      auto store_groups = [&](auto has_res) {
+        constexpr bool HR = decltype(has_res)::value;
+        f32x4_t rv[RD == 2 ? 2 : 1][(HR && RD) ? MI : 1][2];
+        auto loadg = [&](int nq, int slot) {
+          if constexpr (HR && RD > 0) {
+            const int colc = min(cw + nq * 32, p.N - 8);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+              const f32x4_t* rp = (const f32x4_t*)(resid + (long)min(m0 + (wm * MI + mi) * 16 + frow, p.M - 1) * p.ldr + colc);
+              rv[slot][mi][0] = rp[0]; rv[slot][mi][1] = rp[1];
+            }
+          }
+        };
+        if constexpr (RD == 2) loadg(0, 0);
+#pragma unroll
+        for (int nq = 0; nq < NG; ++nq) {
+          if constexpr (RD == 2) { if (nq + 1 < NG) loadg(nq + 1, (nq + 1) & 1); }
+          if constexpr (RD == 1) loadg(nq, 0);
+          const int col = cw + nq * 32;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const int row = m0 + (wm * MI + mi) * 16 + frow;
+            f32x4_t v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              f32x4_t pre = acc[mi][2 * nq + h] * p.alpha + bc[nq][h] + brow[mi];
+              if (p.act == ODIC_ACT_GELU) {
+                pre = gelu_poly4(pre);
+              } else if (p.act != ODIC_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pre[e] = apply_act<true>(pre[e], p.act);
+              }
+              v[h] = pre;
+            }
+            if constexpr (HR) {
+              if constexpr (RD == 0) {
+                const f32x4_t* rp = (const f32x4_t*)(resid + (long)min(row, p.M - 1) * p.ldr + min(col, p.N - 8));
+                v[0] += rp[0]; v[1] += rp[1];
+              } else {
+                v[0] += rv[RD == 2 ? (nq & 1) : 0][mi][0]; v[1] += rv[RD == 2 ? (nq & 1) : 0][mi][1];
+              }
+            }
+            if (row < p.M && col < p.N) {
+              OutT* dst = out + (long)row * p.ldc + col;
+              if constexpr (sizeof(OutT) == 4) {
+                ((f32x4_t*)dst)[0] = v[0]; ((f32x4_t*)dst)[1] = v[1];
+              } else {
+                bf16x8_t pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pk[e] = (short)f32_to_bf16(v[0][e]); pk[4 + e] = (short)f32_to_bf16(v[1][e]); }
+                *(bf16x8_t*)dst = pk;
+              }
+            }
+          }
+        }
+      };
+      if (resid) store_groups(std::true_type{});
+      else store_groups(std::false_type{});
       return;
     }
   }

@@ -23,7 +23,11 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--inner", type=int, default=10)
 ap.add_argument("--vendor", action="store_true")
 ap.add_argument("--x3", action="store_true", help="split-fp16 operands (gemm_x3.hip tile configurations)")
+ap.add_argument("--lib", default=None, help="another build of libodic_hip.so (A/B of kernel changes)")
 a = ap.parse_args()
+if a.lib:
+    from on_device_image_captioning_amd import _hip
+    _hip.LIB_PATH = os.path.abspath(a.lib)
 CFGS = [int(c) for c in a.cfgs.split(",")]
 shapes = []
 for s, C in enumerate((192, 384, 768, 1536)):
