@@ -50,7 +50,7 @@ extern "C" {
 #define ODIC_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ODIC_ABI_VERSION 13
+#define ODIC_ABI_VERSION 14
 int odic_abi_version(void);
 
 /* Human-readable build string ("gfx950 hipcc ..."), static storage. */
@@ -114,6 +114,14 @@ typedef struct odic_gemm_args {
    *     packed W / bias as for the fp32 form above; out = act(rstd·(alpha·A·W'ᵀ − mean·ln_colsum) + bias') + residual. */
   void* out16; int64_t ld16; float* stats_out;
   const float* ln_stats;
+  /* LayerNorm of the A operand computed while A is read (bf16 A-resident tile configurations 50-53 only — the K = 192 /
+   * 384 products of Swin stages 0-1; whole tiles, batch == 1): A = NULL and the operand is
+   *     (x − mean(x)) / sqrt(var(x) + ln_eps)   of each fp32 row of a_ln [M,K] (ld_aln elements),
+   * rounded to bf16 in registers; W and bias are folded by the caller as above (W' = W·diag(gamma), bias' = bias + W·beta), so
+   *     out = act(alpha·LayerNorm(x; gamma, beta)·Wᵀ + bias) + residual.
+   * Replaces norm1 → qkv and norm2 → fc1 (swin_transformer_mod.py:309-310, 338) by one launch each and removes the bf16
+   * copy of the residual stream between them.  NULL = A is the operand. */
+  const float* a_ln; int64_t ld_aln;
 } odic_gemm_args;
 int odic_gemm(const odic_gemm_args* args, void* stream);
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libodic_hip.so")
 
 F32, BF16, FP8, F16, H2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _ERR = {-1: "ODIC_EINVAL (bad shape / alignment / enum)", -2: "ODIC_ENULL (required pointer is NULL)",
         -3: "ODIC_EUNSUPPORTED"}
@@ -32,7 +32,8 @@ class GemmArgs(C.Structure):
                 ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile_cfg", C.c_int32),
                 ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("workspace", C.c_void_p),
                 ("col_scale", C.c_void_p), ("out_scale", C.c_float),
-                ("out16", C.c_void_p), ("ld16", C.c_int64), ("stats_out", C.c_void_p), ("ln_stats", C.c_void_p)]
+                ("out16", C.c_void_p), ("ld16", C.c_int64), ("stats_out", C.c_void_p), ("ln_stats", C.c_void_p),
+                ("a_ln", C.c_void_p), ("ld_aln", C.c_int64)]
 
 
 class BeamState(C.Structure):

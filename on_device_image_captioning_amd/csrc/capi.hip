@@ -18,9 +18,14 @@ extern "C" const char* odic_build_info(void) {
 }
 
 extern "C" int odic_gemm(const odic_gemm_args* a, void* stream) {
-  if (!a || !a->A || !a->W || !a->out) return ODIC_ENULL;
+  if (!a || !a->W || !a->out) return ODIC_ENULL;
+  if (a->a_ln) {                           // LayerNorm-while-reading form: bf16 W, no A, whole fp32 rows of K elements
+    if (a->A || a->in_dtype != ODIC_BF16 || a->ld_aln < a->K || a->batch != 1) return ODIC_EINVAL;
+  } else if (!a->A) {
+    return ODIC_ENULL;
+  }
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return ODIC_EINVAL;
-  if (a->lda < a->K || a->ldw < a->K || a->ldc < a->N) return ODIC_EINVAL;
+  if ((a->A && a->lda < a->K) || a->ldw < a->K || a->ldc < a->N) return ODIC_EINVAL;
   if (a->residual && a->ldr < a->N) return ODIC_EINVAL;
   if (a->act < ODIC_ACT_NONE || a->act > ODIC_ACT_SIGMOID) return ODIC_EINVAL;
   if (a->bias_axis != 0 && a->bias_axis != 1) return ODIC_EINVAL;

@@ -49,6 +49,7 @@ struct Params {
   bf16_raw* out16; long ld16; float* stats_out;
   const float* ln_stats; const float* ln_colsum; float ln_eps;
   int skew_from, skew_to, skew_sleeps;   // blocks [skew_from, skew_to) start skew_sleeps x 64·127 clocks late
+  const float* a_ln; long ld_aln;        // A-resident kernels: fp32 rows whose LayerNorm (no affine) is the A operand
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -996,7 +997,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256sq_kernel(Params p) {
 //     number of stores; anything else is refused and the caller's tuner falls back to the tiled kernel.
 // Grid: row panels x `nsplit` column ranges; the ranges of one panel run on one XCD (its A rows come from that L2).
 // =================================================================================================
-template <int MI, int NI, int KT, int KH, typename OutT, bool RES>
+template <int MI, int NI, int KT, int KH, typename OutT, bool RES, bool LNA = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_apanel_kernel(Params p, int nsplit) {
   constexpr int NW = 4;
   constexpr int BM = NW * MI * 16, BNC = NI * 16;
@@ -1026,11 +1027,82 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_apanel_kernel(Params p, int 
 
   // ---- this wave's rows of A, whole K, as MFMA B-operand fragments: lane (frow, fq) holds A[row frow][32k + 8fq ..]
   bf16x8_t af[2 * KT][MI];
+  if constexpr (LNA) {
+    // LayerNorm while reading: the row's K fp32 values are spread over the four fq lanes (8 per 32-deep step each);
+    // mean and centred variance in two passes over the registers, reduced across lanes frow, frow + 16, + 32, + 48,
+    // then (x - mean)·rstd is rounded to bf16 straight into the fragments (gamma / beta are folded into W / bias).
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const bf16_raw* ar = p.A + (long)(m0 + (wave * MI + mi) * 16 + frow) * p.lda + fq * 8;
+    for (int mi = 0; mi < MI; ++mi) {
+      const float* xr = p.a_ln + (long)(m0 + (wave * MI + mi) * 16 + frow) * p.ld_aln + fq * 8;
+      if constexpr (KT > 3) {
+        // K = 384: 96 fp32 values per lane and row would cost the kernel a resident block — moments in ONE pass over the
+        // loads (shifted by the row's first element, which keeps E[(x-c)²] − E[x-c]² well conditioned), then the row is
+        // read again (L1 / L2) and normalised into the fragments
+        f32x4_t a0 = *(const f32x4_t*)xr;
+        const float c = __shfl(a0[0], frow, 64);                         // x[row][0] (lane fq = 0 holds it)
+        f32x4_t s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 2 * KT; ++k) af[k][mi] = *(const bf16x8_t*)(ar + k * 32);
+        for (int k = 0; k < 2 * KT; ++k) {
+          const f32x4_t u0 = *(const f32x4_t*)(xr + k * 32) - c, u1 = *(const f32x4_t*)(xr + k * 32 + 4) - c;
+          s1 += u0 + u1;
+          s2 += u0 * u0 + u1 * u1;
+          if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);             // (at most 8 row loads in flight: registers)
+        }
+        float t1 = (s1[0] + s1[1]) + (s1[2] + s1[3]), t2 = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+        t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+        t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+        const float m1 = t1 * (1.0f / (64 * KT));
+        const float mean = c + m1;
+        const float rstd = rsqrtf(fmaxf(t2 * (1.0f / (64 * KT)) - m1 * m1, 0.f) + p.ln_eps);
+#pragma unroll
+        for (int k = 0; k < 2 * KT; ++k) {
+          const f32x4_t u0 = (*(const f32x4_t*)(xr + k * 32) - mean) * rstd, u1 = (*(const f32x4_t*)(xr + k * 32 + 4) - mean) * rstd;
+          bf16x8_t f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { f[e] = (short)f32_to_bf16(u0[e]); f[4 + e] = (short)f32_to_bf16(u1[e]); }
+          af[k][mi] = f;
+          if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        continue;
+      }
+      f32x4_t xv[2 * KT][2];
+#pragma unroll
+      for (int k = 0; k < 2 * KT; ++k) { xv[k][0] = *(const f32x4_t*)(xr + k * 32); xv[k][1] = *(const f32x4_t*)(xr + k * 32 + 4); }
+      f32x4_t s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 2 * KT; ++k) s4 += xv[k][0] + xv[k][1];
+      float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum * (1.0f / (64 * KT));
+      f32x4_t q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 2 * KT; ++k) {
+        xv[k][0] -= mean; xv[k][1] -= mean;
+        q4 += xv[k][0] * xv[k][0] + xv[k][1] * xv[k][1];
+      }
+      float ssq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+      ssq += __shfl_xor(ssq, 16, 64);
+      ssq += __shfl_xor(ssq, 32, 64);
+      const float rstd = rsqrtf(ssq * (1.0f / (64 * KT)) + p.ln_eps);
+#pragma unroll
+      for (int k = 0; k < 2 * KT; ++k) {
+        bf16x8_t f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f[e] = (short)f32_to_bf16(xv[k][0][e] * rstd);
+          f[4 + e] = (short)f32_to_bf16(xv[k][1][e] * rstd);
+        }
+        af[k][mi] = f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const bf16_raw* ar = p.A + (long)(m0 + (wave * MI + mi) * 16 + frow) * p.lda + fq * 8;
+#pragma unroll
+      for (int k = 0; k < 2 * KT; ++k) af[k][mi] = *(const bf16x8_t*)(ar + k * 32);
+    }
   }
 
   // ---- W chunk DMA: instruction i of this wave fills 1 KiB = rows 8·rg .. +7 of sub-tile kt, j = i·NW + wave
@@ -1190,6 +1262,12 @@ int launch_apanel(Params& p, int out_dtype, int batch, hipStream_t stream) {
   dim3 grid(8 * ((panels + 7) / 8) * nsplit), block(256);
   const int SHMEM = 2 * (KT / KH) * BNC * 128 + (nchunks + nsplit - 1) / nsplit * BNC * 4;     // W buffers + the block's bias values
   if (SHMEM > 64 * 1024) return ODIC_EUNSUPPORTED;
+  if (p.a_ln) {                       // LayerNorm-while-reading form: bf16 / fp32 output, no residual
+    if (p.residual || (p.ld_aln & 3) || ((uintptr_t)p.a_ln & 15)) return ODIC_EUNSUPPORTED;
+    if (out_dtype == ODIC_BF16) hipLaunchKernelGGL((gemm_bf16_apanel_kernel<MI, NI, KT, KH, bf16_raw, false, true>), grid, block, SHMEM, stream, p, nsplit);
+    else hipLaunchKernelGGL((gemm_bf16_apanel_kernel<MI, NI, KT, KH, float, false, true>), grid, block, SHMEM, stream, p, nsplit);
+    return odic_launch_status();
+  }
   if constexpr (MI <= 2) {
     if (p.residual) {
       if (out_dtype == ODIC_BF16) hipLaunchKernelGGL((gemm_bf16_apanel_kernel<MI, NI, KT, KH, bf16_raw, true>), grid, block, SHMEM, stream, p, nsplit);
@@ -1356,8 +1434,10 @@ constexpr bool kFold = false;
 
 int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
   if (a->ln_colsum && !a->ln_stats) return ODIC_EUNSUPPORTED;          // (the in-kernel moments form is fp32 skinny only)
-  if (a->K % 64 != 0 || a->lda % 8 != 0 || a->ldw % 8 != 0) return ODIC_EINVAL;
+  if (a->K % 64 != 0 || (a->A && a->lda % 8 != 0) || a->ldw % 8 != 0) return ODIC_EINVAL;
   if (((uintptr_t)a->A & 15) || ((uintptr_t)a->W & 15)) return ODIC_EINVAL;
+  if (a->a_ln && (a->tile_cfg < 50 || a->tile_cfg > 53)) return ODIC_EUNSUPPORTED;   // (A-resident kernels only)
+  if (!a->a_ln && !a->A) return ODIC_EINVAL;
   if ((a->strideA % 8) || (a->strideW % 8)) return ODIC_EINVAL;
   Params p;
   p.skew_from = 0; p.skew_to = 0; p.skew_sleeps = 0;
@@ -1370,6 +1450,7 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
   p.ws = a->workspace;
   p.out16 = (bf16_raw*)a->out16; p.ld16 = a->ld16; p.stats_out = a->stats_out;
   p.ln_stats = a->ln_stats; p.ln_colsum = a->ln_colsum; p.ln_eps = a->ln_eps;
+  p.a_ln = a->a_ln; p.ld_aln = a->ld_aln;
   if (p.out16) {          // producer of a folded LayerNorm: whole 32-column groups, vector stores, fp32 output
     if (!p.stats_out || a->out_dtype != ODIC_F32 || a->batch != 1 || (a->N & 31) || (a->ldc & 7) || (a->ld16 & 7) ||
         ((uintptr_t)a->out16 & 15) || ((uintptr_t)a->out & 15) || (a->residual && (a->ldr & 3)))

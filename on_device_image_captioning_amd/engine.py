@@ -112,6 +112,20 @@ class SwinEngine:
                     p = f"{P}.layers.{s}.blocks.{b}"
                     w["qkv_f"] = ops.fold_layernorm_bf16(f32(p + ".attn.qkv.weight"), w["qkv_b"], w["n1w"], w["n1b"])
                     w["fc1_f"] = ops.fold_layernorm_bf16(f32(p + ".mlp.fc1.weight"), w["fc1_b"], w["n2w"], w["n2b"])
+        # bf16 mode, the stage of width 192 (Swin-L stage 0): norm1 → qkv and norm2 → fc1 are ONE launch each — the A-resident
+        # GEMM kernel normalises the fp32 rows while it reads them (odic_gemm_args.a_ln; gamma / beta folded into the
+        # weights): 96 → 85 and 130 → 105 µs per pair at B = 16.  Not at width 384: there the fused form needs the registers
+        # of a resident block and re-reads the fp32 rows once per column range — 95 against 62 µs (tools/ln_read_probe.py).
+        # ODIC_FUSE_BACKBONE_LN_READ=0 keeps the two launches.
+        self.ln_read = precision == "bf16" and not self.fold_ln and os.environ.get("ODIC_FUSE_BACKBONE_LN_READ", "1") == "1"
+        if self.ln_read:
+            for s, (blocks, _) in enumerate(self.stages):
+                if g.stage_dim(s) != 192:
+                    continue
+                for b, w in enumerate(blocks):
+                    p = f"{P}.layers.{s}.blocks.{b}"
+                    w["qkv_lnr"] = ops.fold_layernorm_bf16(f32(p + ".attn.qkv.weight"), w["qkv_b"], w["n1w"], w["n1b"])[:2]
+                    w["fc1_lnr"] = ops.fold_layernorm_bf16(f32(p + ".mlp.fc1.weight"), w["fc1_b"], w["n2w"], w["n2b"])[:2]
         self.fp8_ready = False
         if fp8:
             self._pack_fp8(sd, calibration_images)
@@ -219,6 +233,13 @@ class SwinEngine:
                         ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x, out16=x16, stats_out=stats)
                     else:
                         ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x)
+                elif "qkv_lnr" in w and _amax is None and ops.a_ln_supported(x.shape[0], 3 * C_, C_):
+                    qkv = ops.gemm(None, w["qkv_lnr"][0], w["qkv_lnr"][1], a_ln=x, out_dtype=cdt)
+                    att = ops.window_attention(qkv, w["table"], B, res, C_, heads, ws, w["shift"],
+                                               bias_shifted_prescaled=w["dense"])
+                    ops.gemm(att, w["proj_w"], w["proj_b"], residual=x, out=x, alpha=w["proj_a"])
+                    h = ops.gemm(None, w["fc1_lnr"][0], w["fc1_lnr"][1], a_ln=x, act=ops.ACT_GELU, out_dtype=cdt)
+                    ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x, alpha=w["fc2_a"])
                 else:
                     xn = ops.layernorm(x, w["n1w"], w["n1b"], out_dtype=cdt)
                     if _amax is not None:

@@ -194,7 +194,8 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
          strideR: int = 0, strideC: int = 0, ln_fold: Optional[tuple] = None, tile_cfg: int = -1,
          col_scale: Optional[torch.Tensor] = None, out_scale: float = 1.0,
          out16: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None,
-         ln_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+         ln_stats: Optional[torch.Tensor] = None, a_ln: Optional[torch.Tensor] = None, ln_eps: float = 1e-5
+         ) -> torch.Tensor:
     """out = act(alpha·A·Wᵀ + bias) + residual.  With no explicit dims, A is [..., K] (flattened to
     [M,K]) and W is [N,K], both contiguous.  Explicit dims / leading dimensions / batch strides allow
     strided sub-matrices (elements).  ln_fold = (colsum, eps): W and bias come from fold_layernorm() and
@@ -203,7 +204,11 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
     scale) and `out_scale` the result before an fp8 / fp16 output cast.
     LayerNorm folded across two bf16 products: the PRODUCER (fp32 output) is given `out16` (bf16 [M,N]) and
     `stats_out` (fp32 [M, N/32, 2]); the CONSUMER reads that copy as A with `ln_stats=stats_out` and
-    `ln_fold=(colsum, eps)` from fold_layernorm_bf16()."""
+    `ln_fold=(colsum, eps)` from fold_layernorm_bf16().
+    LayerNorm while reading (A = None, `a_ln` = the fp32 rows [M,K], W / bias from fold_layernorm_bf16()): the bf16
+    A-resident kernels normalise each row in registers — one launch for norm → linear (K = 192 / 384, whole tiles)."""
+    if a_ln is not None:
+        return _gemm_a_ln(a_ln, W, bias, out, act=act, alpha=alpha, out_dtype=out_dtype, ln_eps=ln_eps, tile_cfg=tile_cfg)
     _need_cuda(A, W, bias, residual, out, col_scale, out16, stats_out, ln_stats)
     if A.dtype != W.dtype:
         raise RuntimeError("A and W must share a dtype")
@@ -260,6 +265,46 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
                 f"{M}x{N}x{K}" + (f"x{batch}" if batch > 1 else "")):
         _hip.check(_hip.load().odic_gemm(C.byref(a), _stream()), "odic_gemm")
     return out
+
+
+_A_LN_CANDIDATES = (50, 52, 51, 53)          # the A-resident tile configurations (gemm_bf16_apanel_kernel)
+
+
+def _gemm_a_ln(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor], *, act: int,
+               alpha: float, out_dtype: Optional[torch.dtype], ln_eps: float, tile_cfg: int) -> torch.Tensor:
+    """out = act(alpha·LN0(x)·Wᵀ + bias), LN0 = LayerNorm without affine, computed while the fp32 rows are read
+    (odic_gemm_args.a_ln).  x fp32 [M,K] contiguous, W bf16 [N,K] contiguous."""
+    _need_cuda(x, W, bias, out)
+    if x.dtype != torch.float32 or W.dtype != torch.bfloat16 or not (x.is_contiguous() and W.is_contiguous()):
+        raise RuntimeError("gemm(a_ln=...): contiguous fp32 rows and a contiguous bf16 weight")
+    K = x.shape[-1]
+    M, N = x.numel() // K, W.shape[0]
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=out_dtype or torch.bfloat16, device=x.device)
+    a = _hip.GemmArgs(None, _p(W), _p(bias), None, _p(out), M, N, K, K, K, 0, N, 1, 0, 0, 0, 0, 0, alpha, act, 0,
+                      BF16, dtype_code(out.dtype), tile_cfg, None, float(ln_eps), None, None, 1.0, None, 0, None, None,
+                      _p(x), K)
+    key = ("a_ln", M, N, K, out.dtype, act)
+    cfg = _TILE_CHOICE.get(key) if tile_cfg < 0 else tile_cfg
+    if cfg is None and _TILE_CACHE:
+        cfg = _TILE_CACHE.get(_cache_key(key))
+        if cfg is not None:
+            _TILE_CHOICE[key] = cfg
+    if cfg is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("gemm(a_ln=...): no tile choice for this shape yet — run it once outside graph capture")
+        cfg = _tune_gemm(a, key, out, _A_LN_CANDIDATES)
+        if cfg < 0:
+            raise RuntimeError(f"gemm(a_ln=...): no A-resident tile configuration takes {M}x{N}x{K}")
+    a.tile_cfg = cfg
+    with _timed("gemm_bf16", 2.0 * M * N * K, M * K * 4 + N * K * 2 + M * N * out.element_size(), f"ln+{M}x{N}x{K}"):
+        _hip.check(_hip.load().odic_gemm(C.byref(a), _stream()), "odic_gemm")
+    return out
+
+
+def a_ln_supported(M: int, N: int, K: int) -> bool:
+    """Shapes the LayerNorm-while-reading form takes: K = 192 (128-row panels, 64-column chunks) or 384 (128 / 32)."""
+    return (K == 192 and M % 128 == 0 and N % 64 == 0) or (K == 384 and M % 128 == 0 and N % 32 == 0)
 
 
 def fold_layernorm(W: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):

@@ -510,6 +510,43 @@ def test_gemm_bf16_whole_line_store_epilogue(ops, cfg):
         assert torch.all(wide[:, N:] == 7.0)
 
 
+@pytest.mark.parametrize("cfg,K,bm,bnc", [(50, 192, 256, 64), (52, 192, 128, 64), (51, 384, 128, 32), (53, 384, 128, 64)])
+def test_gemm_bf16_layernorm_while_reading(ops, cfg, K, bm, bnc):
+    """odic_gemm_args.a_ln: the A-resident kernels normalise the fp32 rows while they read them (norm → linear in one
+    launch, gamma / beta folded into W / bias).  Against fp64 LayerNorm → Linear, against the two-launch path
+    (odic_layernorm → bf16, then the tiled product with the same folded weights), on rows with a large common offset
+    (mean >> spread: what the one-pass moments of the K = 384 form must survive) and constant rows (variance 0)."""
+    g = torch.Generator().manual_seed(7 * cfg)
+    M, N = bm * 5, bnc * 6
+    x = torch.randn(M, K, generator=g) * torch.rand(M, 1, generator=g) * 3.0 + torch.randn(M, 1, generator=g) * 40.0
+    x[3] = 5.0                                            # a constant row: (x - mean) = 0, rstd = 1/sqrt(eps)
+    x[4] = 0.0
+    W = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    gamma, beta = 1.0 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    want = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5) @ W.double().T + b.double()
+    Wf, bf, _ = ops.fold_layernorm_bf16(dev(W), dev(b), dev(gamma), dev(beta))
+    xd = dev(x)
+    for name, kw, ref in (("linear", {}, want), ("gelu", dict(act=ops.ACT_GELU), torch.nn.functional.gelu(want))):
+        got = ops.gemm(None, Wf, bf, a_ln=xd, tile_cfg=cfg, out_dtype=torch.bfloat16, **kw)
+        assert got.shape == (M, N) and got.dtype == torch.bfloat16
+        assert_close(got, ref, 1.2e-2, f"cfg{cfg} ln+{name} vs fp64")
+        xn = ops.layernorm(xd, dev(torch.ones(K)), dev(torch.zeros(K)), out_dtype=torch.bfloat16)
+        two = ops.gemm(xn, Wf, bf, tile_cfg=0, out_dtype=torch.bfloat16, **kw)
+        # same bf16 operands up to the rounding of the normalised rows (different summation order of the moments)
+        diff = (got.float() - two.float()).abs()
+        assert float(diff.max()) <= 2e-2 * float(two.float().abs().max()), (cfg, name, float(diff.max()))
+        assert float((diff > 0).float().mean()) < 0.02, (cfg, name, float((diff > 0).float().mean()))
+    got32 = ops.gemm(None, Wf, bf, a_ln=xd, tile_cfg=cfg, out_dtype=torch.float32)
+    assert_close(got32, want, 8e-3, f"cfg{cfg} ln fp32 out")
+    assert torch.isfinite(got32).all()
+    # refused: a residual, a tiled configuration, a row count that is not whole panels
+    with pytest.raises(RuntimeError):
+        ops.gemm(None, Wf, bf, a_ln=xd, tile_cfg=1)
+    with pytest.raises(RuntimeError):
+        ops.gemm(None, Wf, bf, a_ln=xd[: bm + 16].contiguous(), tile_cfg=cfg)
+
+
 def test_gemm_bf16_default_build_rejects_compiled_out_configurations(ops):
     from on_device_image_captioning_amd import _hip
     if b"experimental-gemm" in _hip.load().odic_build_info():
