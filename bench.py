@@ -243,6 +243,12 @@ def roofline_pass(pipe, images):
                 blk["flops"] += times[j][1]
                 blk["bytes"] += times[j][2]
             blk["launches"] += 1
+        elif name == "swin_qkv_attention" and i < len(times) - 1:      # norm1 + qkv + core in one launch, then the proj GEMM
+            for j in (i, i + 1):
+                blk["ms"] += times[j][3]
+                blk["flops"] += times[j][1]
+                blk["bytes"] += times[j][2]
+            blk["launches"] += 1
     if blk["launches"]:
         fam["swin_attention_block(qkv+core+proj)"] = blk
     for (name, flops, nbytes, s, e, detail), (_, _, _, ms) in zip(recs, times):
@@ -294,7 +300,7 @@ def pmc_traffic(name, workload=None, precision="default"):
 
 def roofline_entry(name, d, workload=None, precision="default"):
     sec = d["ms"] * 1e-3
-    mfma = name.startswith("gemm") or name.startswith("swin_attention_block")
+    mfma = name.startswith("gemm") or name.startswith("swin_")      # (incl. the fused norm1 + qkv + attention launch)
     if mfma:
         # gemm_fp8: the block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales) carries the 5 PFLOP/s fp8 rate
         # (MI355X_MICROARCH.md § Matrix cores) — priced against it; gemm_x3 (split fp16): three fp16 MFMAs per

@@ -50,7 +50,7 @@ extern "C" {
 #define ODIC_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ODIC_ABI_VERSION 14
+#define ODIC_ABI_VERSION 15
 int odic_abi_version(void);
 
 /* Human-readable build string ("gfx950 hipcc ..."), static storage. */
@@ -198,6 +198,21 @@ int odic_resize_bilinear_normalize(const uint8_t* src_rgb, int32_t H, int32_t W,
 int odic_window_attention(const void* qkv, const float* bias_table, const float* bias_shifted_prescaled,
                           void* out, int32_t B, int32_t res, int32_t C, int32_t heads, int32_t ws,
                           int32_t shift, float scale, int32_t dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * norm1 → qkv Linear → window attention core of one Swin block in ONE launch (swin_transformer_mod.py:309-334 with
+ * WindowAttention.forward :222-263 up to, not including, the proj Linear), for the stage of width C = 192 (ws = 12):
+ *   x        fp32 [B*res*res, C] (ldx)   the residual stream (token-major, un-shifted, un-partitioned)
+ *   w_qkv_folded bf16 [3C, C], b_qkv_folded fp32 [3C]:  W·diag(gamma) and bias + W·beta of norm1 → qkv (the caller folds the
+ *            LayerNorm's affine part at pack time; the kernel computes (x − mean)/sqrt(var + ln_eps) in registers)
+ *   bias_shifted_prescaled fp32 [heads, 4, 576]   as for odic_window_attention
+ *   out      bf16 [B*res*res, C]   attention output at the un-shifted token positions (ready for the proj Linear)
+ * One block per window keeps its 144 normalised rows as MFMA fragments in registers; q / k / v of a head never leave the
+ * chip.  Results are bit-identical to odic_gemm(a_ln = x, …) followed by odic_window_attention (bf16).
+ * ------------------------------------------------------------------------------------------- */
+int odic_swin_qkv_attention(const float* x, int64_t ldx, const void* w_qkv_folded, const float* b_qkv_folded,
+                            const float* bias_shifted_prescaled, void* out, int32_t B, int32_t res, int32_t C,
+                            int32_t heads, int32_t ws, int32_t shift, float scale, float ln_eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Static expansion (encoder) helpers — layers.py:45-102.  The contractions run through

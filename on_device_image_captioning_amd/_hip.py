@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libodic_hip.so")
 
 F32, BF16, FP8, F16, H2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _ERR = {-1: "ODIC_EINVAL (bad shape / alignment / enum)", -2: "ODIC_ENULL (required pointer is NULL)",
         -3: "ODIC_EUNSUPPORTED"}
@@ -62,6 +62,7 @@ _SIGNATURES = {
     "odic_resize_bilinear_normalize": (C.c_int, [_P, _I32, _I32, _I64, _P, _P, _I32, _P, _P, _I32, _P, _P, _I32,
                                                  C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "odic_window_attention": (C.c_int, [_P, _P, _P, _P] + [_I32] * 6 + [_F, _I32, _P]),
+    "odic_swin_qkv_attention": (C.c_int, [_P, _I64, _P, _P, _P, _P] + [_I32] * 6 + [_F, _F, _P]),
     "odic_stcexp_normalize": (C.c_int, [_P, _P, _P, _I32, _P, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _F, _F, _I32,
                                         _P]),
     "odic_selector_mix": (C.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _P]),

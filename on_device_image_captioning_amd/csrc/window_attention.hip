@@ -516,6 +516,268 @@ __global__ __launch_bounds__(192, 4) void window_attention_bf16_v3_kernel(WinPar
 
 
 // =================================================================================================
+// norm1 → qkv → attention core in ONE launch for the stage of width 192 (Swin-L stage 0): VERDICT r2 #5.
+//
+// Unfused, a stage-0 block at B = 16 writes 170 MB of qkv and reads it back (plus the 57 MB bf16 copy of the
+// normalised rows): LayerNorm 37 µs + qkv product 56 µs + attention core 53 µs.  Here one block of NINE waves owns one
+// window; wave w owns the window's tokens 16w .. 16w+15 for the whole launch:
+//   * it reads its 16 fp32 rows of the residual stream ONCE, normalises them in registers (the row's 192 values sit in
+//     the four fq lanes; gamma / beta are folded into W / bias by the caller) and keeps them as six MFMA B-operand
+//     fragments — 24 registers, never in LDS (the A-resident GEMM's LayerNorm-while-reading form, gemm_bf16.hip);
+//   * per head, the 96 W rows of that head's q / k / v channels (36 KiB, the tiled GEMM's swizzled sub-tile image, rows
+//     permuted so that an accumulator pair is 8 adjacent channels) and the head's packed bias copies (9 KiB) arrive by
+//     LDS-DMA one head ahead; 36 MFMAs give the wave q, k, v of its 16 tokens: q stays in registers — the accumulator
+//     pair IS the Q fragment of the score MFMA — k and v go to the window's K / V images in LDS (16 bytes per lane);
+//   * barrier, then the v3 core above on one query tile per wave (bias as accumulator init, base-2 softmax on the raw
+//     accumulators, P·V through ds_read_b64_tr_b16), 8 bytes x 2 of output per lane;
+//   * the counted wait in front of a head's first barrier is vmcnt(2): that head's DMA was issued BEFORE the previous
+//     head's two stores (vmcnt retires in order), so the stores stay in flight.
+// Bit-identical to LayerNorm-while-reading product + v3 core (same MFMAs in the same K order, the same roundings of
+// q / k / v to bf16): tests/test_hip_ops.py::test_swin_qkv_attention_fused.
+// =================================================================================================
+struct FusedParams {
+  const float* x; long ldx; const bf16_raw* W; const float* bqkv; const float* bias_shifted; bf16_raw* out;
+  int B, res, C, heads, ws, shift, nwin_side;
+  float scale, eps;
+};
+
+__device__ __forceinline__ int wperm32(int r) {            // gemm_bf16.hip's W row permutation inside a 32-row group
+  return 8 * ((r & 15) >> 2) + 4 * ((r >> 4) & 1) + (r & 3);
+}
+
+template <int KT>
+__global__ __launch_bounds__(576, 1) void swin_qkv_attention_kernel(FusedParams p) {
+  constexpr int C = KT * 64;
+  constexpr int WSUB = 96 * 128;                            // one 64-deep sub-tile of a head's 96 W rows
+  constexpr int WBUF = KT * WSUB;
+  constexpr int NWV = 9;
+  static_assert((WBUF / 1024) % NWV == 0, "a head's W image must split evenly over the nine waves");
+  constexpr int WI = WBUF / 1024 / NWV;                     // W DMA instructions per wave and head
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* Wb = lds;                                                                    // 2 x WBUF
+  char* Kp = lds + 2 * WBUF;                                                         // [144][32] bf16, chunk-swizzled
+  char* Vp = Kp + MAXN * HD * 2;                                                     // [160][32] bf16 (rows 144.. zero)
+  char* Bp = Vp + (MAXN + 16) * HD * 2;                                              // 2 x 4 bias copies
+  float* sbq = (float*)(Bp + 2 * 4 * BS_COPY * 4);                                   // qkv bias, 3C floats
+  int* rows = (int*)(sbq + 3 * C);
+  unsigned char* rids = (unsigned char*)(rows + MAXN);
+
+  ODIC_ENCODE_PRIO();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int win = blockIdx.x;
+  const int wpi = p.nwin_side * p.nwin_side;
+  const int b = win / wpi, wrem = win - b * wpi;
+  const int wy = wrem / p.nwin_side, wx = wrem - wy * p.nwin_side;
+  const bool masked = p.shift > 0 && (wy == p.nwin_side - 1 || wx == p.nwin_side - 1);
+  if (tid < MAXN) {
+    WinParams wp;
+    wp.ws = p.ws; wp.shift = p.shift; wp.res = p.res;
+    long r; int rid;
+    slot_to_token(wp, b, wy, wx, tid, r, rid);
+    rows[tid] = (int)r; rids[tid] = (unsigned char)rid;
+  }
+  if (tid < 128) ((unsigned long long*)(Vp + MAXN * HD * 2))[tid] = 0ull;             // 16 x 64 B of padding keys
+  for (int t = tid; t < 3 * C; t += 64 * NWV) sbq[t] = p.bqkv[t];
+
+  // ---- per-head DMA: W rows (part, 32-row group permuted) as KT swizzled sub-tiles, then the head's bias copies
+  int w_off[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int j = i * NWV + wave, kt = j / 12, rg = j - kt * 12;
+    const int srow = lane >> 3, r = rg * 8 + srow;
+    w_off[i] = ((r >> 5) * C + wperm32(r & 31)) * C + kt * 64 + ((lane & 7) ^ srow) * 8;
+  }
+  auto issue = [&](int h, int buf) {
+    const bf16_raw* wb = p.W + (long)h * HD * C;
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wb + w_off[i]), (lptr_t)(Wb + buf * WBUF + (i * NWV + wave) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(p.bias_shifted + (long)h * 4 * BS_COPY + wave * 256 + lane * 4),
+                                     (lptr_t)(Bp + buf * 4 * BS_COPY * 4 + wave * 1024), 16, 0, 0);
+  };
+  issue(0, 0);
+  __syncthreads();                                          // rows[] / rids / bias staged
+
+  // ---- this wave's 16 tokens: LayerNorm in registers → six B-operand fragments (lane (fr, fq): row fr, k = 32kk + 8fq ..)
+  const int slot = wave * 16 + fr;
+  const int orow = rows[slot];
+  bf16x8_t af[2 * KT];
+  {
+    const float* xr = p.x + (long)orow * p.ldx + fq * 8;
+    f32x4_t xv[2 * KT][2];
+#pragma unroll
+    for (int k = 0; k < 2 * KT; ++k) { xv[k][0] = *(const f32x4_t*)(xr + k * 32); xv[k][1] = *(const f32x4_t*)(xr + k * 32 + 4); }
+    f32x4_t s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2 * KT; ++k) s4 += xv[k][0] + xv[k][1];
+    float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / C);
+    f32x4_t q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2 * KT; ++k) {
+      xv[k][0] -= mean; xv[k][1] -= mean;
+      q4 += xv[k][0] * xv[k][0] + xv[k][1] * xv[k][1];
+    }
+    float ssq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+    ssq += __shfl_xor(ssq, 16, 64);
+    ssq += __shfl_xor(ssq, 32, 64);
+    const float rstd = rsqrtf(ssq * (1.0f / C) + p.eps);
+#pragma unroll
+    for (int k = 0; k < 2 * KT; ++k) {
+      bf16x8_t f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f[e] = (short)f32_to_bf16(xv[k][0][e] * rstd); f[4 + e] = (short)f32_to_bf16(xv[k][1][e] * rstd); }
+      af[k] = f;
+    }
+  }
+
+  const float scale2 = p.scale * 1.4426950408889634f;
+  const float mask_acc = 100.0f / p.scale;
+  const int voff = ((4 * fq + (fr >> 2)) * HD + 4 * (fr & 3)) * 2;
+  int koffs[9];
+#pragma unroll
+  for (int kt = 0; kt < 9; ++kt) {
+    const int key0 = kt * 16 + fq * 4;
+    const int jy = key0 / 12, jx0 = key0 - jy * 12;
+    koffs[kt] = (jx0 - jy * 24) * 4;
+  }
+  int bias_org;                                             // byte address of the query's origin in ITS bias copy
+  {
+    const int iy = slot / 12, ix = slot - iy * 12;
+    const int sft = (11 - ix) & 3;
+    bias_org = (sft * BS_COPY + (iy + 11) * 24 + 11 - ix - sft) * 4;
+  }
+  const unsigned my_rid = rids[slot];
+
+  __builtin_amdgcn_s_waitcnt(0x0070);                       // vmcnt(0) lgkmcnt(0): x rows and head 0's DMA
+  for (int h = 0; h < p.heads; ++h) {
+    const int buf = h & 1;
+    if (h) __builtin_amdgcn_s_waitcnt(0x0F72);              // vmcnt(2): this head's DMA landed, last head's stores may fly
+    __builtin_amdgcn_s_barrier();                           // ... for every wave; everyone is done with K / V / the other buffers
+    if (h + 1 < p.heads) issue(h + 1, buf ^ 1);
+
+    // ---- q, k, v of this wave's tokens for head h: [96 channels] x [16 tokens], K = C
+    f32x4_t acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const char* lw = Wb + buf * WBUF + fr * 128;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int chunk = ((kk * 4 + fq) ^ (fr & 7)) << 4;
+        bf16x8_t wf[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) wf[t] = *(const bf16x8_t*)(lw + kt * WSUB + t * 16 * 128 + chunk);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], af[2 * kt + kk], acc[t], 0, 0, 0);
+      }
+    }
+    bf16x8_t qkv8[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const f32x4_t* sb = (const f32x4_t*)(sbq + u * C + h * HD + fq * 8);
+      const f32x4_t v0 = acc[2 * u] + sb[0], v1 = acc[2 * u + 1] + sb[1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { qkv8[u][e] = (short)f32_to_bf16(v0[e]); qkv8[u][4 + e] = (short)f32_to_bf16(v1[e]); }
+    }
+    const bf16x8_t q = qkv8[0];
+    *(bf16x8_t*)(Kp + slot * HD * 2 + ((fq ^ ((fr >> 2) & 3)) << 4)) = qkv8[1];
+    *(bf16x8_t*)(Vp + slot * HD * 2 + (fq << 4)) = qkv8[2];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                           // the window's K / V of head h are complete
+
+    // ---- the v3 core on this wave's query tile
+    int koff = (fr * HD + ((fq ^ ((fr >> 2) & 3)) * 8)) * 2, vo = voff, bb = bias_org;
+    asm volatile("" : "+v"(koff), "+v"(vo), "+v"(bb));
+    const char* kbase = Kp + koff;
+    const char* vbase = Vp + vo;
+    const char* bbase = Bp + buf * 4 * BS_COPY * 4 + bb;
+    f32x4_t sc[9];
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) sc[kt] = *(const f32x4_t*)(bbase + koffs[kt]);
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+      const bf16x8_t kf = *(const bf16x8_t*)(kbase + kt * 16 * HD * 2);
+      sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, q, sc[kt], 0, 0, 0);
+    }
+    if (masked) {
+#pragma unroll
+      for (int kt = 0; kt < 9; ++kt) {
+        const unsigned kr = *(const unsigned*)&rids[kt * 16 + fq * 4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (((kr >> (8 * j)) & 0xff) != my_rid) sc[kt][j] -= mask_acc;
+      }
+    }
+    float m = max3f(sc[0][0], sc[0][1], sc[0][2]);
+    m = max3f(m, sc[0][3], sc[1][0]);
+    m = max3f(m, sc[1][1], sc[1][2]);
+#pragma unroll
+    for (int kt = 2; kt < 9; kt += 2) {
+      m = max3f(m, sc[kt - 1][3], sc[kt][0]);
+      m = max3f(m, sc[kt][1], sc[kt][2]);
+      if (kt + 1 < 9) {
+        m = max3f(m, sc[kt][3], sc[kt + 1][0]);
+        m = max3f(m, sc[kt + 1][1], sc[kt + 1][2]);
+      } else {
+        m = fmaxf(m, sc[kt][3]);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const f32x2_t s2 = {scale2, scale2};
+    const f32x2_t c2 = {-m * scale2, -m * scale2};
+    f32x2_t lsum = {0.f, 0.f};
+    bf16x4_t pk[9];
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const f32x2_t a = f32x2_t{sc[kt][2 * hh], sc[kt][2 * hh + 1]} * s2 + c2;
+        const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        lsum += e;
+        pk[kt][2 * hh] = (short)f32_to_bf16(e[0]);
+        pk[kt][2 * hh + 1] = (short)f32_to_bf16(e[1]);
+      }
+    }
+    float l = lsum[0] + lsum[1];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv_l = __builtin_amdgcn_rcpf(l);
+    f32x4_t oacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+      const bf16x4_t lo4 = pk[2 * s5];
+      const bf16x4_t hi4 = s5 < 4 ? pk[2 * s5 + (s5 < 4)] : bf16x4_t{0, 0, 0, 0};
+      const bf16x8_t pf = bf16x8_t{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s_t*)(vbase + (32 * s5) * HD * 2 + nt * 32));
+        const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s_t*)(vbase + (32 * s5 + 16) * HD * 2 + nt * 32));
+        const bf16x8_t vf = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        oacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[nt], 0, 0, 0);
+      }
+    }
+    bf16_raw* dst = p.out + (long)orow * C + h * HD + fq * 4;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      ushort4 o4;
+      o4.x = f32_to_bf16(oacc[nt][0] * inv_l); o4.y = f32_to_bf16(oacc[nt][1] * inv_l);
+      o4.z = f32_to_bf16(oacc[nt][2] * inv_l); o4.w = f32_to_bf16(oacc[nt][3] * inv_l);
+      *(ushort4*)(dst + nt * 16) = o4;
+    }
+  }
+}
+
+
+// =================================================================================================
 // Split-fp16 ("h2") flavour of the v3 kernel — the attention core of the near-exact fast mode (`precision='x3'`).
 // q, k, v arrive as hi + lo fp16 pairs (odic_common.h; a head's 32 channels are 128 bytes: [8 hi | 8 lo] x 4) and
 // both contractions run as three fp16 MFMAs each:  S = Kh·Qh + Kh·Ql + Kl·Qh,  O = Vh·Ph + Vh·Pl + Vl·Ph  with
@@ -748,5 +1010,27 @@ extern "C" int odic_window_attention(const void* qkv, const float* bias_table, c
   } else {
     return ODIC_EINVAL;
   }
+  return odic_launch_status();
+}
+
+/* norm1 → qkv → attention core of one Swin block in one launch (stage width 192; see swin_qkv_attention_kernel). */
+extern "C" int odic_swin_qkv_attention(const float* x, int64_t ldx, const void* w_qkv_folded, const float* b_qkv_folded,
+                                       const float* bias_shifted_prescaled, void* out, int32_t B, int32_t res, int32_t C,
+                                       int32_t heads, int32_t ws, int32_t shift, float scale, float ln_eps, void* stream) {
+  if (!x || !w_qkv_folded || !b_qkv_folded || !bias_shifted_prescaled || !out) return ODIC_ENULL;
+  if (B <= 0 || ws != 12 || res % ws || heads * HD != C || shift < 0 || shift >= ws || ldx < C) return ODIC_EINVAL;
+  if (C != 192) return ODIC_EUNSUPPORTED;
+  if (((uintptr_t)x & 15) || (ldx & 3) || ((uintptr_t)w_qkv_folded & 15) || ((uintptr_t)out & 7) ||
+      ((uintptr_t)bias_shifted_prescaled & 15) || ((uintptr_t)b_qkv_folded & 3) || (long)B * res * res >= 2147483647L)
+    return ODIC_EINVAL;
+  FusedParams p;
+  p.x = x; p.ldx = ldx; p.W = (const bf16_raw*)w_qkv_folded; p.bqkv = b_qkv_folded; p.bias_shifted = bias_shifted_prescaled;
+  p.out = (bf16_raw*)out; p.B = B; p.res = res; p.C = C; p.heads = heads; p.ws = ws; p.shift = shift;
+  p.nwin_side = res / ws; p.scale = scale; p.eps = ln_eps;
+  constexpr int SHMEM = 2 * 3 * 96 * 128 + MAXN * HD * 2 + (MAXN + 16) * HD * 2 + 2 * 4 * BS_COPY * 4 + 3 * 192 * 4 + MAXN * 4 + MAXN;
+  auto k = swin_qkv_attention_kernel<3>;
+  static bool done = false;
+  if (!done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM); done = true; }
+  hipLaunchKernelGGL(k, dim3(B * p.nwin_side * p.nwin_side), dim3(576), SHMEM, (hipStream_t)stream, p);
   return odic_launch_status();
 }

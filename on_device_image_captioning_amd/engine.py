@@ -118,6 +118,7 @@ class SwinEngine:
         # of a resident block and re-reads the fp32 rows once per column range — 95 against 62 µs (tools/ln_read_probe.py).
         # ODIC_FUSE_BACKBONE_LN_READ=0 keeps the two launches.
         self.ln_read = precision == "bf16" and not self.fold_ln and os.environ.get("ODIC_FUSE_BACKBONE_LN_READ", "1") == "1"
+        self.fuse_qkv_attn = os.environ.get("ODIC_FUSE_QKV_ATTENTION", "1") == "1"
         if self.ln_read:
             for s, (blocks, _) in enumerate(self.stages):
                 if g.stage_dim(s) != 192:
@@ -234,9 +235,14 @@ class SwinEngine:
                     else:
                         ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x)
                 elif "qkv_lnr" in w and _amax is None and ops.a_ln_supported(x.shape[0], 3 * C_, C_):
-                    qkv = ops.gemm(None, w["qkv_lnr"][0], w["qkv_lnr"][1], a_ln=x, out_dtype=cdt)
-                    att = ops.window_attention(qkv, w["table"], B, res, C_, heads, ws, w["shift"],
-                                               bias_shifted_prescaled=w["dense"])
+                    if self.fuse_qkv_attn and ws == 12 and w["dense"] is not None:
+                        # norm1 → qkv → attention core: one launch, q / k / v never leave the chip
+                        att = ops.swin_qkv_attention(x, w["qkv_lnr"][0], w["qkv_lnr"][1], w["dense"], B, res, C_, heads,
+                                                     ws, w["shift"])
+                    else:
+                        qkv = ops.gemm(None, w["qkv_lnr"][0], w["qkv_lnr"][1], a_ln=x, out_dtype=cdt)
+                        att = ops.window_attention(qkv, w["table"], B, res, C_, heads, ws, w["shift"],
+                                                   bias_shifted_prescaled=w["dense"])
                     ops.gemm(att, w["proj_w"], w["proj_b"], residual=x, out=x, alpha=w["proj_a"])
                     h = ops.gemm(None, w["fc1_lnr"][0], w["fc1_lnr"][1], a_ln=x, act=ops.ACT_GELU, out_dtype=cdt)
                     ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x, alpha=w["fc2_a"])

@@ -451,6 +451,25 @@ def shifted_bias_prescaled(bias_table: torch.Tensor, ws: int, scale: float) -> t
     return out.contiguous()
 
 
+def swin_qkv_attention(x: torch.Tensor, w_folded: torch.Tensor, b_folded: torch.Tensor, bias_shifted_prescaled: torch.Tensor,
+                       B: int, res: int, C_: int, heads: int, ws: int, shift: int, *, eps: float = 1e-5,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """norm1 → qkv → attention core in one launch (odic_swin_qkv_attention; width 192, ws 12).  x fp32 [B·res², C] contiguous,
+    (w_folded, b_folded) from fold_layernorm_bf16(qkv.weight, qkv.bias, norm1.weight, norm1.bias) → bf16 [B·res², C]."""
+    _need_cuda(x, w_folded, b_folded, bias_shifted_prescaled, out)
+    if x.dtype != torch.float32 or w_folded.dtype != torch.bfloat16 or not (x.is_contiguous() and w_folded.is_contiguous()):
+        raise RuntimeError("swin_qkv_attention: contiguous fp32 rows and a contiguous bf16 folded weight")
+    if out is None:
+        out = torch.empty(B * res * res, C_, dtype=torch.bfloat16, device=x.device)
+    nwh = B * (res // ws) ** 2 * heads
+    with _timed("swin_qkv_attention", 2.0 * B * res * res * C_ * 3 * C_ + nwh * 2654208.0,
+                B * res * res * C_ * (4 + 2) + 3 * C_ * C_ * 2, f"res{res}h{heads}"):
+        _hip.check(_hip.load().odic_swin_qkv_attention(_p(x), C_, _p(w_folded), _p(b_folded), _p(bias_shifted_prescaled),
+                                                      _p(out), B, res, C_, heads, ws, shift, (C_ // heads) ** -0.5, eps,
+                                                      _stream()), "odic_swin_qkv_attention")
+    return out
+
+
 def window_attention(qkv: torch.Tensor, bias_table: torch.Tensor, B: int, res: int, C_: int, heads: int, ws: int,
                      shift: int, *, scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
                      bias_shifted_prescaled: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -547,6 +547,61 @@ def test_gemm_bf16_layernorm_while_reading(ops, cfg, K, bm, bnc):
         ops.gemm(None, Wf, bf, a_ln=xd[: bm + 16].contiguous(), tile_cfg=cfg)
 
 
+@pytest.mark.parametrize("shift", [0, 6])
+def test_swin_qkv_attention_fused(ops, shift):
+    """odic_swin_qkv_attention (norm1 → qkv → attention core of a width-192 Swin block in one launch) against the two
+    launches it replaces — the LayerNorm-while-reading product + the bf16 window-attention kernel: the same MFMAs in the
+    same order and the same bf16 roundings of q / k / v, so the outputs must agree bit for bit — and against an fp64
+    restatement of swin_transformer_mod.py:309-334 / :222-263 (roll, partition, bias, SW-MSA mask, softmax, reverse)."""
+    B, res, C_, heads, ws = 2, 24, 192, 6, 12
+    g = torch.Generator().manual_seed(11 + shift)
+    L = res * res
+    x = torch.randn(B * L, C_, generator=g) * 1.5 + torch.randn(B * L, 1, generator=g) * 3.0
+    W = torch.randn(3 * C_, C_, generator=g) * 0.06
+    bq = torch.randn(3 * C_, generator=g) * 0.2
+    gamma, beta = 1.0 + 0.2 * torch.randn(C_, generator=g), 0.1 * torch.randn(C_, generator=g)
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.3
+    Wf, bf, _ = ops.fold_layernorm_bf16(dev(W), dev(bq), dev(gamma), dev(beta))
+    dense = ops.shifted_bias_prescaled(dev(table), ws, 32 ** -0.5)
+    xd = dev(x)
+    got = ops.swin_qkv_attention(xd, Wf, bf, dense, B, res, C_, heads, ws, shift)
+    qkv = ops.gemm(None, Wf, bf, a_ln=xd, out_dtype=torch.bfloat16)
+    two = ops.window_attention(qkv, dev(table), B, res, C_, heads, ws, shift, bias_shifted_prescaled=dense)
+    assert got.dtype == torch.bfloat16 and got.shape == two.shape
+    assert torch.equal(got, two), float((got.float() - two.float()).abs().max())
+
+    # fp64 restatement of the reference block (to the tolerance of bf16 q / k / v / P)
+    xn = torch.nn.functional.layer_norm(x.double(), (C_,), gamma.double(), beta.double(), 1e-5)
+    qkv64 = (xn @ W.double().T + bq.double()).view(B, res, res, 3 * C_)
+    if shift:
+        qkv64 = torch.roll(qkv64, (-shift, -shift), (1, 2))
+    nw = res // ws
+    win = qkv64.view(B, nw, ws, nw, ws, 3, heads, 32).permute(0, 1, 3, 5, 6, 2, 4, 7).reshape(B * nw * nw, 3, heads, ws * ws, 32)
+    q, k, v = win[:, 0] * 32 ** -0.5, win[:, 1], win[:, 2]
+    coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0) + (ws - 1)
+    idx = rel[..., 0] * (2 * ws - 1) + rel[..., 1]
+    att = q @ k.transpose(-1, -2) + table.double()[idx.view(-1)].view(ws * ws, ws * ws, heads).permute(2, 0, 1)[None]
+    if shift:
+        img = torch.zeros(res, res)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[hs, wsl] = cnt
+                cnt += 1
+        mw = img.view(nw, ws, nw, ws).permute(0, 2, 1, 3).reshape(nw * nw, ws * ws)
+        mask = (mw[:, None, :] - mw[:, :, None] != 0).double() * -100.0
+        att = att.view(B, nw * nw, heads, ws * ws, ws * ws) + mask[None, :, None]
+        att = att.view(B * nw * nw, heads, ws * ws, ws * ws)
+    o = (torch.softmax(att, -1) @ v).transpose(1, 2).reshape(B, nw, nw, ws, ws, C_).permute(0, 1, 3, 2, 4, 5).reshape(B, res, res, C_)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    assert_close(got, o.reshape(B * L, C_), 2.5e-2, f"fused qkv+attention shift {shift} vs fp64")
+    with pytest.raises(RuntimeError):                               # only width 192
+        ops.swin_qkv_attention(dev(torch.zeros(B * L, 384)), dev(torch.zeros(1152, 384)).bfloat16(), dev(torch.zeros(1152)),
+                               ops.shifted_bias_prescaled(dev(torch.zeros(529, 12)), ws, 32 ** -0.5), B, res, 384, 12, ws, 0)
+
+
 def test_gemm_bf16_default_build_rejects_compiled_out_configurations(ops):
     from on_device_image_captioning_amd import _hip
     if b"experimental-gemm" in _hip.load().odic_build_info():
