@@ -19,6 +19,7 @@
 //   * a 16-byte ds_read_b128 fragment feeds TWO fp8 MFMAs (its low and high 8 bytes are the K-slots of two
 //     consecutive 32-deep steps; A and W use the same assignment, and a dot product does not care about K order).
 #include "odic_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -196,6 +197,151 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_lowp_nt_kernel(Params p) 
   const float* resid = p.residual;
   OutT* out = (OutT*)p.out;
   const bool ld_ok = ((p.ldc & 7) == 0) && (!resid || (p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  // The vector path (as gemm_bf16.hip's): vmcnt retires in order and counts stores, so a bias / scale / residual load
+  // between two groups of stores waits for every store before it.  All per-column factors are requested before the first
+  // store, the residual rows of column group g + 1 before the stores of group g; fp16 outputs leave in whole 128-byte
+  // lines (two column groups exchanged between lanes frow and frow ^ 8), fp8 outputs in 64-byte half lines (a wave's 64
+  // columns are 64 bytes) instead of 32-byte quarters.
+  if (ld_ok && (p.N & 7) == 0 && !p.bias_axis &&
+      (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) && (!p.col_scale || (reinterpret_cast<uintptr_t>(p.col_scale) & 15) == 0)) {
+    constexpr int NG = NI / 2;
+    const int cw = n0 + wn * NI * 16 + fq * 8;
+    f32x4_t bc[NG][2], cs[NG][2];
+#pragma unroll
+    for (int nq = 0; nq < NG; ++nq) {
+      bc[nq][0] = bc[nq][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      cs[nq][0] = cs[nq][1] = f32x4_t{1.f, 1.f, 1.f, 1.f};
+    }
+    if (bias) {
+#pragma unroll
+      for (int nq = 0; nq < NG; ++nq) {
+        const f32x4_t* bp = (const f32x4_t*)(bias + min(cw + nq * 32, p.N - 8));
+        bc[nq][0] = bp[0]; bc[nq][1] = bp[1];
+      }
+    }
+    if (p.col_scale) {
+#pragma unroll
+      for (int nq = 0; nq < NG; ++nq) {
+        const f32x4_t* sp = (const f32x4_t*)(p.col_scale + min(cw + nq * 32, p.N - 8));
+        cs[nq][0] = sp[0]; cs[nq][1] = sp[1];
+      }
+    }
+    auto value = [&](int mi, int nq, f32x4_t* v) {               // the finished 8 values of accumulator pair (mi, nq), no residual
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4_t pre = acc[mi][2 * nq + h] * (cs[nq][h] * p.alpha) + bc[nq][h];
+        if (p.act == ODIC_ACT_GELU) {
+          pre = gelu_poly4(pre);
+        } else if (p.act != ODIC_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pre[e] = apply_act<true>(pre[e], p.act);
+        }
+        v[h] = pre * p.out_scale;
+      }
+    };
+    if constexpr (sizeof(OutT) != 4 && NI % 4 == 0) {
+      // 16-bit / 8-bit outputs (never with a residual in the product path; one is handled row by row): lane exchange
+      const bool lo = frow < 8;
+      if (!resid && (p.N & 63) == 0) {
+#pragma unroll
+        for (int q2 = 0; q2 < NI / 4; ++q2) {
+          const int cbase = n0 + wn * NI * 16 + q2 * 64;
+          if (cbase >= p.N) continue;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const int r16 = m0 + (wm * MI + mi) * 16;
+            f32x4_t v0[2], v1[2];
+            value(mi, 2 * q2, v0);
+            value(mi, 2 * q2 + 1, v1);
+            const int ra = r16 + (frow & 7);
+            if constexpr (sizeof(OutT) == 2) {
+              f16x8_t p0, p1;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                p0[e] = (_Float16)v0[0][e]; p0[4 + e] = (_Float16)v0[1][e];
+                p1[e] = (_Float16)v1[0][e]; p1[4 + e] = (_Float16)v1[1][e];
+              }
+              const i32x4_t own0 = __builtin_bit_cast(i32x4_t, p0), own1 = __builtin_bit_cast(i32x4_t, p1);
+              const i32x4_t send = lo ? own1 : own0;
+              i32x4_t recv;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) recv[e] = __builtin_amdgcn_update_dpp(0, send[e], 0x128, 0xf, 0xf, false);   // row_ror:8
+              f16_t* dst = (f16_t*)out + (long)ra * p.ldc + cbase + (lo ? 0 : 32) + fq * 8;
+              if (ra < p.M) *(i32x4_t*)dst = lo ? own0 : recv;
+              if (ra + 8 < p.M) *(i32x4_t*)(dst + 8 * p.ldc) = lo ? recv : own1;
+            } else {
+              typedef __attribute__((ext_vector_type(2))) int i32x2_t;
+              const i32x2_t own0 = {(int)pack_fp8x4(v0[0][0], v0[0][1], v0[0][2], v0[0][3]), (int)pack_fp8x4(v0[1][0], v0[1][1], v0[1][2], v0[1][3])};
+              const i32x2_t own1 = {(int)pack_fp8x4(v1[0][0], v1[0][1], v1[0][2], v1[0][3]), (int)pack_fp8x4(v1[1][0], v1[1][1], v1[1][2], v1[1][3])};
+              const i32x2_t send = lo ? own1 : own0;
+              i32x2_t recv;
+#pragma unroll
+              for (int e = 0; e < 2; ++e) recv[e] = __builtin_amdgcn_update_dpp(0, send[e], 0x128, 0xf, 0xf, false);
+              fp8_raw* dst = (fp8_raw*)out + (long)ra * p.ldc + cbase + (lo ? 0 : 32) + fq * 8;
+              if (ra < p.M) *(i32x2_t*)dst = lo ? own0 : recv;
+              if (ra + 8 < p.M) *(i32x2_t*)(dst + 8 * p.ldc) = lo ? recv : own1;
+            }
+          }
+        }
+        return;
+      }
+    }
+    // fp32 output (the proj product: + residual) and everything the exchange form does not take
+    auto store_groups = [&](auto has_res) {
+      constexpr bool HR = decltype(has_res)::value;
+      constexpr int RD = (HR && sizeof(OutT) == 4 && NW <= 8) ? 2 : 0;       // residual prefetch depth (registers: 2 x MI x 8)
+      f32x4_t rv[RD ? 2 : 1][RD ? MI : 1][2];
+      auto loadg = [&](int nq, int slot) {
+        if constexpr (RD > 0) {
+          const int colc = min(cw + nq * 32, p.N - 8);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const f32x4_t* rp = (const f32x4_t*)(resid + (long)min(m0 + (wm * MI + mi) * 16 + frow, p.M - 1) * p.ldr + colc);
+            rv[slot][mi][0] = rp[0]; rv[slot][mi][1] = rp[1];
+          }
+        }
+      };
+      if constexpr (RD == 2) loadg(0, 0);
+#pragma unroll
+      for (int nq = 0; nq < NG; ++nq) {
+        if constexpr (RD == 2) { if (nq + 1 < NG) loadg(nq + 1, (nq + 1) & 1); }
+        const int col = cw + nq * 32;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int row = m0 + (wm * MI + mi) * 16 + frow;
+          f32x4_t v[2];
+          value(mi, nq, v);
+          if constexpr (HR) {
+            if constexpr (RD == 0) {
+              const f32x4_t* rp = (const f32x4_t*)(resid + (long)min(row, p.M - 1) * p.ldr + min(col, p.N - 8));
+              v[0] += rp[0]; v[1] += rp[1];
+            } else {
+              v[0] += rv[nq & 1][mi][0]; v[1] += rv[nq & 1][mi][1];
+            }
+          }
+          if (row < p.M && col < p.N) {
+            OutT* dst = out + (long)row * p.ldc + col;
+            if constexpr (sizeof(OutT) == 4) {
+              ((f32x4_t*)dst)[0] = v[0]; ((f32x4_t*)dst)[1] = v[1];
+            } else if constexpr (sizeof(OutT) == 2) {
+              f16x8_t pk;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { pk[e] = (_Float16)v[0][e]; pk[4 + e] = (_Float16)v[1][e]; }
+              *(f16x8_t*)dst = pk;
+            } else {
+              uint2 pk;
+              pk.x = pack_fp8x4(v[0][0], v[0][1], v[0][2], v[0][3]);
+              pk.y = pack_fp8x4(v[1][0], v[1][1], v[1][2], v[1][3]);
+              *(uint2*)dst = pk;
+            }
+          }
+        }
+      }
+    };
+    if (resid) store_groups(std::true_type{});
+    else store_groups(std::false_type{});
+    return;
+  }
 #pragma unroll
   for (int nq = 0; nq < NI / 2; ++nq) {
     const int col = n0 + wn * NI * 16 + nq * 32 + fq * 8;
