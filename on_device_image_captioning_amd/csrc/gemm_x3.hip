@@ -19,6 +19,7 @@
 //   * out_dtype ODIC_H2: the lane's 8 adjacent columns are exactly one h2 group → 32 contiguous bytes (hi | lo).
 //   * GELU is the exact erf form: this mode exists to reproduce the fp32 reference's captions.
 #include "odic_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -155,6 +156,71 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_nt_kernel(Params p) {
   constexpr bool OUT_H2 = __is_same(OutT, h2_t);
   char* out = (char*)p.out + bz * p.strideC * 4;
   const bool ld_ok = ((p.ldc & 7) == 0) && (!resid || (p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 31) == 0);
+  // The vector path (as gemm_bf16.hip's): vmcnt retires in order and counts stores, so a bias or residual load between two
+  // groups of stores waits for every store before it — every bias value is requested before the first store, the residual
+  // rows of column group g + 1 before the stores of group g (4- and 6-wave blocks; wider blocks request a group's rows together).
+  if (ld_ok && (p.N & 7) == 0 && !p.bias_axis && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) {
+    constexpr int NG = NI / 2;
+    const int cw = n0 + wn * NI * 16 + fq * 8;
+    f32x4_t bc[NG][2];
+#pragma unroll
+    for (int nq = 0; nq < NG; ++nq) bc[nq][0] = bc[nq][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int nq = 0; nq < NG; ++nq) {
+        const f32x4_t* bp = (const f32x4_t*)(bias + min(cw + nq * 32, p.N - 8));
+        bc[nq][0] = bp[0]; bc[nq][1] = bp[1];
+      }
+    }
+    auto store_groups = [&](auto has_res) {
+      constexpr bool HR = decltype(has_res)::value;
+      constexpr int RD = HR ? (NW <= 6 ? 2 : 1) : 0;
+      f32x4_t rv[RD == 2 ? 2 : 1][RD ? MI : 1][2];
+      auto loadg = [&](int nq, int slot) {
+        if constexpr (RD > 0) {
+          const int colc = min(cw + nq * 32, p.N - 8);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const f32x4_t* rp = (const f32x4_t*)(resid + (long)min(m0 + (wm * MI + mi) * 16 + frow, p.M - 1) * p.ldr + colc);
+            rv[slot][mi][0] = rp[0]; rv[slot][mi][1] = rp[1];
+          }
+        }
+      };
+      if constexpr (RD == 2) loadg(0, 0);
+#pragma unroll
+      for (int nq = 0; nq < NG; ++nq) {
+        if constexpr (RD == 2) { if (nq + 1 < NG) loadg(nq + 1, (nq + 1) & 1); }
+        if constexpr (RD == 1) loadg(nq, 0);
+        const int col = cw + nq * 32;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int row = m0 + (wm * MI + mi) * 16 + frow;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = acc[mi][2 * nq + (e >> 2)][e & 3] * p.alpha + bc[nq][e >> 2][e & 3];
+            v[e] = apply_act<false>(x, p.act);
+          }
+          if constexpr (HR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[RD == 2 ? (nq & 1) : 0][mi][e >> 2][e & 3];
+          }
+          if (row < p.M && col < p.N) {
+            if constexpr (OUT_H2) {
+              h2_store8((h2_t*)out + (long)row * p.ldc + col, v);
+            } else {
+              float* dst = (float*)out + (long)row * p.ldc + col;
+              ((f32x4_t*)dst)[0] = f32x4_t{v[0], v[1], v[2], v[3]};
+              ((f32x4_t*)dst)[1] = f32x4_t{v[4], v[5], v[6], v[7]};
+            }
+          }
+        }
+      }
+    };
+    if (resid) store_groups(std::true_type{});
+    else store_groups(std::false_type{});
+    return;
+  }
 #pragma unroll
   for (int nq = 0; nq < NI / 2; ++nq) {
     const int col = n0 + wn * NI * 16 + nq * 32 + fq * 8;
