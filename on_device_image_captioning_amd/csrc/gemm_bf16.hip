@@ -74,8 +74,14 @@ __device__ __forceinline__ int wperm(int r) {
 // (separate instantiations: the extra registers of the fold must not cost the plain products their occupancy)
 // (second launch bound: the 4-wave blocks with 128 accumulator registers per lane must stay within 256 registers
 //  so that two of them share a CU — left alone hipcc takes 158 + 128)
-template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK, typename OutT, int LNF = 0>
-__global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && MI * NI == 32) ? 2 : 1) void gemm_bf16_nt_kernel(Params p) {
+// KS = 2: TWO groups of NWM x NWN waves share the tile and its LDS stages; group g takes the 32-deep half g of every 64-deep
+// K-tile (half the MFMAs each), group 1 hands its accumulators to group 0 through LDS after the loop (a fixed order of
+// additions: deterministic, but not the summation order of the KS = 1 form).  For the tiles whose wave count does not fill
+// four SIMDs evenly — 144 x 192 is six waves, the exact-round tile of the 9216 x 768 products — this gives every SIMD three
+// waves.  Only group 0 stages (its vmcnt waits precede the barrier both groups meet at) and only group 0 stores.
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK, typename OutT, int LNF = 0, int KS = 1>
+__global__ __launch_bounds__(64 * NWM * NWN * KS, (NWM * NWN * KS == 4 && MI * NI == 32) ? 2 : 1) void gemm_bf16_nt_kernel(Params p) {
+  static_assert(KS == 1 || (KS == 2 && BK == 64 && LNF == 0), "the K-split form is two groups on 64-deep K-tiles");
   constexpr int NW = NWM * NWN;
   constexpr int ROWB = BK * 2;                 // bytes per LDS row
   constexpr int RPI = 1024 / ROWB;             // rows per 1-KiB DMA instruction
@@ -89,7 +95,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && MI * NI == 32) ?
   constexpr int D = NSTAGE - 1;                                        // prefetch distance in K-tiles
   extern __shared__ __attribute__((aligned(16))) char lds[];          // stage0 {A,W} | stage1 {A,W}
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int kg = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((tid >> 6) / NW);      // K group of this wave
+  const int wave = KS == 1 ? (tid >> 6) : __builtin_amdgcn_readfirstlane((tid >> 6) % NW);
   const int wm = wave / NWN, wn = wave % NWN;
   ODIC_ENCODE_PRIO();
   if ((int)blockIdx.x >= p.skew_from && (int)blockIdx.x < p.skew_to)
@@ -130,6 +138,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && MI * NI == 32) ?
   }
 
   auto stage = [&](int buf, int kt) {
+    if (KS == 2 && kg != 0) return;
     char* la = lds + buf * STAGE;
     char* lw = la + A_BYTES;
 #pragma unroll
@@ -201,7 +210,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && MI * NI == 32) ?
     const char* la = lds + cur * STAGE + (wm * MI * 16 + frow) * ROWB;
     const char* lw = lds + cur * STAGE + A_BYTES + (wn * NI * 16 + frow) * ROWB;
 #pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
+    for (int kq = 0; kq < BK / 32 / KS; ++kq) {
+      const int kk = KS == 1 ? kq : kg;
       bf16x8_t af[MI], wf[NI];
       const int chunk = swz<BK>(kk * 4 + fq, frow) << 4;
 #pragma unroll
@@ -214,6 +224,23 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && MI * NI == 32) ?
         for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
     }
+  }
+  if constexpr (KS == 2) {
+    // group 1 → LDS → group 0 (the stages are free: every wave is past its last fragment read at the barrier)
+    f32x4_t* red = (f32x4_t*)lds + (long)wave * MI * NI * 64 + lane;
+    __builtin_amdgcn_s_barrier();
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) red[(i * NI + j) * 64] = acc[i][j];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] += red[(i * NI + j) * 64];
   }
   // ---- epilogue.  With the operands swapped the 16x16 accumulator is Cᵀ: lane (frow, fq) register j
   //      holds output row frow, W-slot 4·fq + j.  The W rows were staged permuted (wperm above), so
@@ -1280,10 +1307,12 @@ int launch_apanel(Params& p, int out_dtype, int batch, hipStream_t stream) {
   return odic_launch_status();
 }
 
-template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK = 64, bool FOLD = false>
+template <int NWM, int NWN, int MI, int NI, int NSTAGE, int BK = 64, bool FOLD = false, int KS = 1>
 int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
   constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
-  constexpr int SHMEM = NSTAGE * (BM + BN) * BK * 2 + BM * 8;          // + (mean, rstd) per row of the tile
+  constexpr int SH_STAGES = NSTAGE * (BM + BN) * BK * 2 + BM * 8;      // + (mean, rstd) per row of the tile
+  constexpr int SH_RED = KS == 2 ? NWM * NWN * MI * NI * 1024 : 0;     // K-split: one group's accumulators
+  constexpr int SHMEM = SH_STAGES > SH_RED ? SH_STAGES : SH_RED;
   if (p.K % BK != 0) return ODIC_EINVAL;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
   // XCD partition: fewest column parts whose W sub-panel (N/pn x K bf16) fits ~2.5 MiB of the 4 MiB L2
@@ -1299,9 +1328,9 @@ int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
       const int r = ((xm + 1) * p.tiles_m / pm - xm * p.tiles_m / pm) * ((xn + 1) * p.tiles_n / pn - xn * p.tiles_n / pn);
       if (r > max_rect) max_rect = r;
     }
-  dim3 grid(8 * max_rect, 1, batch), block(64 * NWM * NWN);
-  auto kb = gemm_bf16_nt_kernel<NWM, NWN, MI, NI, NSTAGE, BK, bf16_raw>;
-  auto kf = gemm_bf16_nt_kernel<NWM, NWN, MI, NI, NSTAGE, BK, float>;
+  dim3 grid(8 * max_rect, 1, batch), block(64 * NWM * NWN * KS);
+  auto kb = gemm_bf16_nt_kernel<NWM, NWN, MI, NI, NSTAGE, BK, bf16_raw, 0, KS>;
+  auto kf = gemm_bf16_nt_kernel<NWM, NWN, MI, NI, NSTAGE, BK, float, 0, KS>;
   if (SHMEM > 64 * 1024) {
     static bool done = false;       // idempotent; racing first calls set the same value
     if (!done) {
@@ -1491,6 +1520,7 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     case 44: return launch_cfg<3, 1, 3, 6, 2, 64>(p, a->out_dtype, a->batch, stream);  // 144 x 96,   3 waves, 2 stages (60 KiB)
     case 45: return launch_cfg<3, 3, 3, 6, 3, 32>(p, a->out_dtype, a->batch, stream);  // 144 x 288 x 32, 9 waves, 3 stages (81 KiB)
     case 46: return launch_cfg<3, 1, 3, 6, 3, 64>(p, a->out_dtype, a->batch, stream);  // 144 x 96,   3 waves, 3 stages (90 KiB)
+    case 47: return launch_cfg<3, 2, 3, 6, 2, 64, false, 2>(p, a->out_dtype, a->batch, stream);  // 144 x 192, TWO K groups of 6 waves (108 KiB)
     // A-resident streaming kernels for K = 192 / 384 (whole tiles only; see gemm_bf16_apanel_kernel)
     case 50: return launch_apanel<4, 4, 3>(p, a->out_dtype, a->batch, stream);  // K = 192: 256-row panels, 64-column chunks
     case 51: return launch_apanel<2, 2, 6>(p, a->out_dtype, a->batch, stream);  // K = 384: 128-row panels, 32-column chunks

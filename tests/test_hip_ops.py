@@ -29,7 +29,8 @@ def dev(t):
     return t.to("cuda")
 
 
-DEFAULT_BF16_TILE_CFGS = [0, 1, 2, 7, 10]        # what the default build of gemm_bf16.hip carries
+DEFAULT_BF16_TILE_CFGS = [0, 1, 2, 7, 10, 40, 41, 42, 43, 44, 45, 46, 47]        # what the default build of gemm_bf16.hip carries
+                                                                          # (50-53, whole tiles only: tested on their own)
 
 
 def _need_experimental_gemm():
@@ -429,7 +430,7 @@ def test_gemm_bf16_256sq_phase_pipeline(ops):
 PERSISTENT_CFGS = [16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27]
 
 
-@pytest.mark.parametrize("cfg", list(range(12)) + [13, 14, 15, 28, 29, 30, 31, 32, 33] + PERSISTENT_CFGS)
+@pytest.mark.parametrize("cfg", list(range(12)) + [13, 14, 15, 28, 29, 30, 31, 32, 33, 40, 41, 42, 43, 44, 45, 46, 47] + PERSISTENT_CFGS)
 def test_gemm_bf16_every_tile_config(ops, cfg):
     """Each tile / pipeline-depth / BK instantiation — one block per tile (0..11) and persistent with dynamic tile
     scheduling (16 + c) — against fp64 on ragged shapes (M, N not multiples of any tile) with every epilogue
@@ -442,6 +443,12 @@ def test_gemm_bf16_every_tile_config(ops, cfg):
         want = torch.relu(0.5 * (A.double() @ Wt.double().T) + b.double()) + r.double()
         got = ops.gemm(dev(A), dev(Wt), dev(b), dev(r), act=2, alpha=0.5, out_dtype=torch.float32, tile_cfg=cfg)
         assert_close(got, want, 2e-4, f"cfg{cfg} {M}x{N}x{K}")
+    # bf16 output through the vector epilogues (N % 8 == 0 / N % 64 == 0), whole and ragged row tiles, a long K
+    for (M, N, K) in ((576, 576, 256), (300, 320, 192), (290, 192, 1536)):
+        A, Wt, b = rnd(M, K, seed=5).bfloat16(), rnd(N, K, seed=6, scale=0.05).bfloat16(), rnd(N, seed=7)
+        want = torch.nn.functional.gelu(A.double() @ Wt.double().T + b.double())
+        got = ops.gemm(dev(A), dev(Wt), dev(b), act=1, out_dtype=torch.bfloat16, tile_cfg=cfg)
+        assert_close(got, want, 6e-3, f"cfg{cfg} bf16 out {M}x{N}x{K}")
 
 
 @pytest.mark.parametrize("cfg,K,bm,bnc", [(50, 192, 256, 64), (52, 192, 128, 64), (51, 384, 128, 32), (53, 384, 128, 64)])
