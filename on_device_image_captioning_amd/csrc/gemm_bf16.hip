@@ -1521,6 +1521,10 @@ int odic_gemm_bf16_launch(const odic_gemm_args* a, hipStream_t stream) {
     case 45: return launch_cfg<3, 3, 3, 6, 3, 32>(p, a->out_dtype, a->batch, stream);  // 144 x 288 x 32, 9 waves, 3 stages (81 KiB)
     case 46: return launch_cfg<3, 1, 3, 6, 3, 64>(p, a->out_dtype, a->batch, stream);  // 144 x 96,   3 waves, 3 stages (90 KiB)
     case 47: return launch_cfg<3, 2, 3, 6, 2, 64, false, 2>(p, a->out_dtype, a->batch, stream);  // 144 x 192, TWO K groups of 6 waves (108 KiB)
+    // 64 x 64 tiles (4 waves of 32 x 32): the expansion encoder's products are 2304 rows (or 16 batches of 144) by 512 columns —
+    // 72 tiles of 128 x 128 leave 184 of the 256 CUs idle while each tile walks a K of 512 ... 2048 alone
+    case 48: return launch_cfg<2, 2, 2, 2, 3, 64>(p, a->out_dtype, a->batch, stream);  // 64 x 64, 3 stages (48 KiB)
+    case 49: return launch_cfg<2, 2, 2, 2, 2, 64>(p, a->out_dtype, a->batch, stream);  // 64 x 64, 2 stages (32 KiB)
     // A-resident streaming kernels for K = 192 / 384 (whole tiles only; see gemm_bf16_apanel_kernel)
     case 50: return launch_apanel<4, 4, 3>(p, a->out_dtype, a->batch, stream);  // K = 192: 256-row panels, 64-column chunks
     case 51: return launch_apanel<2, 2, 6>(p, a->out_dtype, a->batch, stream);  // K = 384: 128-row panels, 32-column chunks

@@ -29,7 +29,7 @@ def dev(t):
     return t.to("cuda")
 
 
-DEFAULT_BF16_TILE_CFGS = [0, 1, 2, 7, 10, 40, 41, 42, 43, 44, 45, 46, 47]        # what the default build of gemm_bf16.hip carries
+DEFAULT_BF16_TILE_CFGS = [0, 1, 2, 7, 10, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49]        # what the default build of gemm_bf16.hip carries
                                                                           # (50-53, whole tiles only: tested on their own)
 
 
@@ -430,7 +430,7 @@ def test_gemm_bf16_256sq_phase_pipeline(ops):
 PERSISTENT_CFGS = [16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27]
 
 
-@pytest.mark.parametrize("cfg", list(range(12)) + [13, 14, 15, 28, 29, 30, 31, 32, 33, 40, 41, 42, 43, 44, 45, 46, 47] + PERSISTENT_CFGS)
+@pytest.mark.parametrize("cfg", list(range(12)) + [13, 14, 15, 28, 29, 30, 31, 32, 33, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49] + PERSISTENT_CFGS)
 def test_gemm_bf16_every_tile_config(ops, cfg):
     """Each tile / pipeline-depth / BK instantiation — one block per tile (0..11) and persistent with dynamic tile
     scheduling (16 + c) — against fp64 on ragged shapes (M, N not multiples of any tile) with every epilogue
