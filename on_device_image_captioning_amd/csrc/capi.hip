@@ -20,7 +20,7 @@ extern "C" const char* odic_build_info(void) {
 extern "C" int odic_gemm(const odic_gemm_args* a, void* stream) {
   if (!a || !a->W || !a->out) return ODIC_ENULL;
   if (a->a_ln) {                           // LayerNorm-while-reading form: bf16 W, no A, whole fp32 rows of K elements
-    if (a->A || a->in_dtype != ODIC_BF16 || a->ld_aln < a->K || a->batch != 1) return ODIC_EINVAL;
+    if (a->A || (a->in_dtype != ODIC_BF16 && a->in_dtype != ODIC_H2) || a->ld_aln < a->K || a->batch != 1) return ODIC_EINVAL;
   } else if (!a->A) {
     return ODIC_ENULL;
   }

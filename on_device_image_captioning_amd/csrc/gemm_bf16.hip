@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_apanel_kernel(Params p, int 
       float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
-      const float mean = sum * (1.0f / (64 * KT));
+      const float mean = sum / (float)(64 * KT);       // (a true division: a constant row then normalises to exactly 0)
       f32x4_t q4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 2 * KT; ++k) {
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_apanel_kernel(Params p, int 
       float ssq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
       ssq += __shfl_xor(ssq, 16, 64);
       ssq += __shfl_xor(ssq, 32, 64);
-      const float rstd = rsqrtf(ssq * (1.0f / (64 * KT)) + p.ln_eps);
+      const float rstd = rsqrtf(ssq / (float)(64 * KT) + p.ln_eps);
 #pragma unroll
       for (int k = 0; k < 2 * KT; ++k) {
         bf16x8_t f;

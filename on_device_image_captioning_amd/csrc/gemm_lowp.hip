@@ -226,17 +226,23 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_lowp_nt_kernel(Params p) 
         cs[nq][0] = sp[0]; cs[nq][1] = sp[1];
       }
     }
+    // (alpha and out_scale live in VGPRs: a packed multiply by one scalar of an SGPR pair is the `op_sel` source-selection
+    //  form the ISA lint forbids — DESIGN.md §5)
+    float alpha_v = p.alpha, oscale_v = p.out_scale;
+    asm volatile("" : "+v"(alpha_v), "+v"(oscale_v));
+#pragma unroll
+    for (int nq = 0; nq < NG; ++nq) { cs[nq][0] *= alpha_v; cs[nq][1] *= alpha_v; }
     auto value = [&](int mi, int nq, f32x4_t* v) {               // the finished 8 values of accumulator pair (mi, nq), no residual
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        f32x4_t pre = acc[mi][2 * nq + h] * (cs[nq][h] * p.alpha) + bc[nq][h];
+        f32x4_t pre = acc[mi][2 * nq + h] * cs[nq][h] + bc[nq][h];
         if (p.act == ODIC_ACT_GELU) {
           pre = gelu_poly4(pre);
         } else if (p.act != ODIC_ACT_NONE) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) pre[e] = apply_act<true>(pre[e], p.act);
         }
-        v[h] = pre * p.out_scale;
+        v[h] = pre * oscale_v;
       }
     };
     if constexpr (sizeof(OutT) != 4 && NI % 4 == 0) {

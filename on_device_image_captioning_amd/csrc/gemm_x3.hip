@@ -276,6 +276,205 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_nt_kernel(Params p) {
   }
 }
 
+// =================================================================================================
+// A-resident streaming form for the K = 192 products of Swin stage 0 (tile configs 20 / 21) — gemm_bf16.hip's
+// gemm_bf16_apanel_kernel on split-fp16 operands.  Those products are output-bandwidth-bound (fc1: 453 MB of h2 output for
+// 44 GFLOP) and the tiled kernel spends 2-3x a device copy's time on them (profiles/r03_gemm_x3_tile_sweep.txt: 260 us).
+//   * a wave keeps its 16·MI rows of A over the whole K as hi / lo MFMA fragments in registers (2 x 4 registers per row
+//     tile and 32-deep step) — read once from the h2 tensor, or, LNA, from the fp32 rows of the residual stream, normalised
+//     in registers and split into hi + lo there (LayerNorm while reading: gamma / beta folded into W / bias by the caller);
+//   * the four waves walk the output columns in chunks of 16·NI; a W chunk (16·NI rows x K in the planar swizzled image of
+//     the tiled kernel, 24 KiB) arrives by LDS-DMA one chunk ahead; one barrier per chunk; the counted wait in front of it
+//     is vmcnt(stores of a chunk): the chunk's DMA was issued before the previous chunk's stores;
+//   * bias through LDS; whole tiles only (refused otherwise: the caller's tuner falls back to the tiled kernel).
+// Same MFMAs in the same order as the tiled kernel: bit-identical (tests/test_x3_gpu.py).
+// =================================================================================================
+struct PanelParams {
+  const char* A; const float* a_ln; const char* W; const float* bias; void* out;
+  int M, N, K;
+  long lda, ld_aln, ldw, ldc;
+  float alpha, ln_eps; int act;
+};
+
+template <int MI, int NI, int KT, typename OutT, bool LNA>
+__global__ __launch_bounds__(256, 2) void gemm_x3_apanel_kernel(PanelParams p, int nsplit) {
+  constexpr int NW = 4;
+  constexpr int BM = NW * MI * 16, BNC = NI * 16;
+  constexpr int SUB = BNC * ROWB;                        // one 32-deep K-tile of a W chunk
+  constexpr int CHUNK = KT * SUB;
+  static_assert(CHUNK % (1024 * NW) == 0 && NI % 2 == 0, "whole DMA instructions per wave; the epilogue pairs column tiles");
+  constexpr int INSTR = CHUNK / 1024 / NW;
+  constexpr int RG = BNC / 8;
+  constexpr bool OUT_H2 = __is_same(OutT, h2_t);
+  constexpr int NST = MI * (NI / 2) * 2;                 // 16-byte stores per wave per chunk (32 bytes per lane and pair)
+  extern __shared__ __attribute__((aligned(16))) char lds[];          // W chunk buffers 0 | 1 | the block's bias values
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ODIC_ENCODE_PRIO();
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int split = idx % nsplit, panel = (idx / nsplit) * 8 + xcd;
+  if (panel >= p.M / BM) return;
+  const int nchunks = p.N / BNC;
+  const int c0 = split * nchunks / nsplit, c1 = (split + 1) * nchunks / nsplit;
+  if (c0 >= c1) return;
+  const int m0 = panel * BM;
+  const int frow = lane & 15, fq = lane >> 4;
+
+  f16x8_t ah[KT][MI], al[KT][MI];
+  if constexpr (LNA) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const float* xr = p.a_ln + (long)(m0 + (wave * MI + mi) * 16 + frow) * p.ld_aln + fq * 8;
+      f32x4_t xv[KT][2];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) { xv[k][0] = *(const f32x4_t*)(xr + k * 32); xv[k][1] = *(const f32x4_t*)(xr + k * 32 + 4); }
+      f32x4_t s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < KT; ++k) s4 += xv[k][0] + xv[k][1];
+      float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      asm volatile("" : "+v"(sum));       // (keeps hipcc's SLP pass from pairing the row tiles' scalar moments into packed
+                                          //  fp32 ops with `op_sel` source selection — tests/test_isa_lint.py)
+      const float mean = sum / (float)(32 * KT);       // (a true division: a constant row then normalises to exactly 0)
+      f32x4_t q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        xv[k][0] -= mean; xv[k][1] -= mean;
+        q4 += xv[k][0] * xv[k][0] + xv[k][1] * xv[k][1];
+      }
+      float ssq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+      ssq += __shfl_xor(ssq, 16, 64);
+      ssq += __shfl_xor(ssq, 32, 64);
+      asm volatile("" : "+v"(ssq));
+      const float rstd = rsqrtf(ssq / (float)(32 * KT) + p.ln_eps);
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        f16x8_t h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { f16_t hh, ll; h2_split(xv[k][e >> 2][e & 3] * rstd, hh, ll); h[e] = hh; l[e] = ll; }
+        ah[k][mi] = h; al[k][mi] = l;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const char* ar = p.A + ((long)(m0 + (wave * MI + mi) * 16 + frow) * p.lda) * 4 + fq * 32;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {             // k-group 4k + fq of the row: [8 hi | 8 lo]
+        ah[k][mi] = *(const f16x8_t*)(ar + k * 128);
+        al[k][mi] = *(const f16x8_t*)(ar + k * 128 + 16);
+      }
+    }
+  }
+
+  // ---- W chunk DMA: instruction i of this wave fills 1 KiB = rows 8·rg .. +7 of K-tile kt, j = i·NW + wave
+  int w_off[INSTR];                                     // byte offsets inside a chunk
+#pragma unroll
+  for (int i = 0; i < INSTR; ++i) {
+    const int j = i * NW + wave, kt = j / RG, rg = j - kt * RG;
+    const int srow = lane >> 3, r = rg * 8 + srow;
+    const int simg = swz(lane & 7, srow);
+    const int smem_chunk = simg < 4 ? 2 * simg : 2 * (simg - 4) + 1;
+    w_off[i] = wperm(r) * (int)p.ldw * 4 + kt * ROWB + smem_chunk * 16;
+  }
+  auto issue = [&](int c, int buf) {
+    const char* wb = p.W + (long)c * BNC * p.ldw * 4;
+    char* lb = lds + buf * CHUNK;
+#pragma unroll
+    for (int i = 0; i < INSTR; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wb + w_off[i]), (lptr_t)(lb + (i * NW + wave) * 1024), 16, 0, 0);
+  };
+  char* out = (char*)p.out;
+  issue(c0, 0);
+  float* sbias = (float*)(lds + 2 * CHUNK);
+  for (int t = tid; t < (c1 - c0) * BNC; t += 256) sbias[t] = p.bias ? p.bias[c0 * BNC + t] : 0.f;
+  __builtin_amdgcn_s_waitcnt(0x0070);                                  // vmcnt(0) lgkmcnt(0) (the builtin: hipcc must see it)
+  const int ch_hi = swz(fq, frow) << 4, ch_lo = swz(4 + fq, frow) << 4;
+  for (int c = c0; c < c1; ++c) {
+    if (c != c0) __builtin_amdgcn_s_waitcnt(0x0F70 | (NST & 15) | ((NST >> 4) << 14));      // vmcnt(NST)
+    __builtin_amdgcn_s_barrier();
+    const int buf = (c - c0) & 1;
+    if (c + 1 < c1) issue(c + 1, buf ^ 1);
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const char* lw = lds + buf * CHUNK + frow * ROWB;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      f16x8_t wh[NI], wl[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        wh[ni] = *(const f16x8_t*)(lw + kt * SUB + ni * 16 * ROWB + ch_hi);
+        wl[ni] = *(const f16x8_t*)(lw + kt * SUB + ni * 16 * ROWB + ch_lo);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ni], ah[kt][mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], al[kt][mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], ah[kt][mi], acc[mi][ni], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int nq = 0; nq < NI / 2; ++nq) {
+      const int col = c * BNC + nq * 32 + fq * 8;
+      const f32x4_t* sb = (const f32x4_t*)(sbias + (c - c0) * BNC + nq * 32 + fq * 8);
+      const f32x4_t b0 = sb[0], b1 = sb[1];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = m0 + (wave * MI + mi) * 16 + frow;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = acc[mi][2 * nq + (e >> 2)][e & 3] * p.alpha + (e < 4 ? b0[e & 3] : b1[e & 3]);
+          v[e] = apply_act<false>(x, p.act);
+        }
+        if constexpr (OUT_H2) {
+          h2_store8((h2_t*)out + (long)row * p.ldc + col, v);
+        } else {
+          float* dst = (float*)out + (long)row * p.ldc + col;
+          ((f32x4_t*)dst)[0] = f32x4_t{v[0], v[1], v[2], v[3]};
+          ((f32x4_t*)dst)[1] = f32x4_t{v[4], v[5], v[6], v[7]};
+        }
+      }
+    }
+  }
+}
+
+template <int MI, int NI, int KT>
+int launch_panel(const odic_gemm_args* a, hipStream_t stream) {
+  constexpr int BM = 4 * MI * 16, BNC = NI * 16;
+  if (a->batch != 1 || a->K != KT * 32 || a->M % BM != 0 || a->N % BNC != 0 || a->bias_axis != 0 || a->residual)
+    return ODIC_EUNSUPPORTED;
+  if ((a->ldc & 7) || ((uintptr_t)a->out & 31) || (long)BNC * a->ldw * 4 >= (1L << 30)) return ODIC_EUNSUPPORTED;
+  if (a->a_ln && ((a->ld_aln & 3) || ((uintptr_t)a->a_ln & 15))) return ODIC_EUNSUPPORTED;
+  PanelParams p;
+  p.A = (const char*)a->A; p.a_ln = a->a_ln; p.W = (const char*)a->W; p.bias = a->bias; p.out = a->out;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ld_aln = a->ld_aln; p.ldw = a->ldw; p.ldc = a->ldc;
+  p.alpha = a->alpha; p.ln_eps = a->ln_eps; p.act = a->act;
+  const int panels = a->M / BM, nchunks = a->N / BNC;
+  int nsplit = nchunks;
+  for (int d = 1; d <= nchunks; ++d)
+    if (nchunks % d == 0 && (long)panels * d >= 1536) { nsplit = d; break; }
+  dim3 grid(8 * ((panels + 7) / 8) * nsplit), block(256);
+  const int SHMEM = 2 * KT * BNC * ROWB + (nchunks + nsplit - 1) / nsplit * BNC * 4;
+  if (SHMEM > 64 * 1024) return ODIC_EUNSUPPORTED;
+  const bool h2 = a->out_dtype == ODIC_H2;
+  if (a->a_ln) {
+    if (h2) hipLaunchKernelGGL((gemm_x3_apanel_kernel<MI, NI, KT, h2_t, true>), grid, block, SHMEM, stream, p, nsplit);
+    else hipLaunchKernelGGL((gemm_x3_apanel_kernel<MI, NI, KT, float, true>), grid, block, SHMEM, stream, p, nsplit);
+  } else {
+    if (h2) hipLaunchKernelGGL((gemm_x3_apanel_kernel<MI, NI, KT, h2_t, false>), grid, block, SHMEM, stream, p, nsplit);
+    else hipLaunchKernelGGL((gemm_x3_apanel_kernel<MI, NI, KT, float, false>), grid, block, SHMEM, stream, p, nsplit);
+  }
+  return odic_launch_status();
+}
+
 template <int NWM, int NWN, int MI, int NI, int NSTAGE>
 int launch(Params& p, int out_dtype, int batch, hipStream_t stream) {
   constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
@@ -315,8 +514,12 @@ int odic_gemm_x3_launch(const odic_gemm_args* a, hipStream_t stream) {
   if (a->ln_colsum || a->col_scale || a->out16 || a->ln_stats) return ODIC_EUNSUPPORTED;
   if (a->out_dtype != ODIC_F32 && a->out_dtype != ODIC_H2) return ODIC_EINVAL;
   // h2 rows are whole [8 hi | 8 lo] groups and K-tiles are four of them
-  if (a->K % 32 != 0 || a->lda % 8 != 0 || a->ldw % 8 != 0 || (a->strideA % 8) || (a->strideW % 8)) return ODIC_EINVAL;
+  if (a->K % 32 != 0 || (a->A && a->lda % 8 != 0) || a->ldw % 8 != 0 || (a->strideA % 8) || (a->strideW % 8)) return ODIC_EINVAL;
   if (((uintptr_t)a->A & 31) || ((uintptr_t)a->W & 31)) return ODIC_EINVAL;
+  if (a->a_ln && a->tile_cfg != 20 && a->tile_cfg != 21) return ODIC_EUNSUPPORTED;   // (A-resident kernels only)
+  if (!a->a_ln && !a->A) return ODIC_EINVAL;
+  if (a->tile_cfg == 20) return launch_panel<2, 2, 6>(a, stream);      // K = 192: 128-row panels, 32-column chunks
+  if (a->tile_cfg == 21) return launch_panel<1, 2, 6>(a, stream);      // K = 192:  64-row panels
   if (a->out_dtype == ODIC_H2 && ((a->ldc % 8) || (a->strideC % 8) || ((uintptr_t)a->out & 31))) return ODIC_EINVAL;
   Params p;
   p.A = (const char*)a->A; p.W = (const char*)a->W; p.bias = a->bias; p.residual = a->residual; p.out = a->out;

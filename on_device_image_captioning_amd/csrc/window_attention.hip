@@ -615,7 +615,7 @@ __global__ __launch_bounds__(576, 1) void swin_qkv_attention_kernel(FusedParams 
     float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    const float mean = sum * (1.0f / C);
+    const float mean = sum / (float)C;                // (as gemm_bf16.hip's LayerNorm-while-reading form: the two must agree bit for bit)
     f32x4_t q4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 2 * KT; ++k) {
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(576, 1) void swin_qkv_attention_kernel(FusedParams 
     float ssq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
     ssq += __shfl_xor(ssq, 16, 64);
     ssq += __shfl_xor(ssq, 32, 64);
-    const float rstd = rsqrtf(ssq * (1.0f / C) + p.eps);
+    const float rstd = rsqrtf(ssq / (float)C + p.eps);
 #pragma unroll
     for (int k = 0; k < 2 * KT; ++k) {
       bf16x8_t f;

@@ -117,16 +117,27 @@ class SwinEngine:
         # weights): 96 → 85 and 130 → 105 µs per pair at B = 16.  Not at width 384: there the fused form needs the registers
         # of a resident block and re-reads the fp32 rows once per column range — 95 against 62 µs (tools/ln_read_probe.py).
         # ODIC_FUSE_BACKBONE_LN_READ=0 keeps the two launches.
-        self.ln_read = precision == "bf16" and not self.fold_ln and os.environ.get("ODIC_FUSE_BACKBONE_LN_READ", "1") == "1"
-        self.fuse_qkv_attn = os.environ.get("ODIC_FUSE_QKV_ATTENTION", "1") == "1"
+        # (split-fp16 mode: the same form exists — gemm_x3.hip tile configs 20 / 21 with a_ln — and is 1 % faster, but folding
+        #  gamma into the weights changes WHICH near-ties of the xavier checkpoint round the other way: 255 / 256 captions equal
+        #  to fp32 instead of 256 / 256 — the mode exists for that equality, so it is opt-in there: ODIC_FUSE_BACKBONE_LN_READ=x3)
+        lr = os.environ.get("ODIC_FUSE_BACKBONE_LN_READ", "1")
+        self.ln_read = not self.fold_ln and ((precision == "bf16" and lr != "0") or (precision == "x3" and lr == "x3"))
+        self.fuse_qkv_attn = precision == "bf16" and os.environ.get("ODIC_FUSE_QKV_ATTENTION", "1") == "1"
         if self.ln_read:
             for s, (blocks, _) in enumerate(self.stages):
                 if g.stage_dim(s) != 192:
                     continue
                 for b, w in enumerate(blocks):
                     p = f"{P}.layers.{s}.blocks.{b}"
-                    w["qkv_lnr"] = ops.fold_layernorm_bf16(f32(p + ".attn.qkv.weight"), w["qkv_b"], w["n1w"], w["n1b"])[:2]
-                    w["fc1_lnr"] = ops.fold_layernorm_bf16(f32(p + ".mlp.fc1.weight"), w["fc1_b"], w["n2w"], w["n2b"])[:2]
+                    if precision == "bf16":
+                        w["qkv_lnr"] = ops.fold_layernorm_bf16(f32(p + ".attn.qkv.weight"), w["qkv_b"], w["n1w"], w["n1b"])[:2] + (1.0,)
+                        w["fc1_lnr"] = ops.fold_layernorm_bf16(f32(p + ".mlp.fc1.weight"), w["fc1_b"], w["n2w"], w["n2b"])[:2] + (1.0,)
+                    else:       # split fp16: the folded weight goes through the same power-of-two packing as every x3 weight
+                        for name, wk, bk, nw, nb in (("qkv_lnr", ".attn.qkv.weight", "qkv_b", "n1w", "n1b"),
+                                                     ("fc1_lnr", ".mlp.fc1.weight", "fc1_b", "n2w", "n2b")):
+                            Wg, b2, _ = ops.fold_layernorm(f32(p + wk), w[bk], w[nw], w[nb])
+                            op, alpha = pack_operand(Wg, self.cdt)
+                            w[name] = (op, b2, alpha)
         self.fp8_ready = False
         if fp8:
             self._pack_fp8(sd, calibration_images)
@@ -234,17 +245,18 @@ class SwinEngine:
                         ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x, out16=x16, stats_out=stats)
                     else:
                         ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x)
-                elif "qkv_lnr" in w and _amax is None and ops.a_ln_supported(x.shape[0], 3 * C_, C_):
+                elif "qkv_lnr" in w and _amax is None and ops.a_ln_supported(x.shape[0], 3 * C_, C_, cdt):
                     if self.fuse_qkv_attn and ws == 12 and w["dense"] is not None:
                         # norm1 → qkv → attention core: one launch, q / k / v never leave the chip
                         att = ops.swin_qkv_attention(x, w["qkv_lnr"][0], w["qkv_lnr"][1], w["dense"], B, res, C_, heads,
                                                      ws, w["shift"])
                     else:
-                        qkv = ops.gemm(None, w["qkv_lnr"][0], w["qkv_lnr"][1], a_ln=x, out_dtype=cdt)
+                        qkv = ops.gemm(None, w["qkv_lnr"][0], w["qkv_lnr"][1], a_ln=x, out_dtype=cdt, alpha=w["qkv_lnr"][2])
                         att = ops.window_attention(qkv, w["table"], B, res, C_, heads, ws, w["shift"],
                                                    bias_shifted_prescaled=w["dense"])
                     ops.gemm(att, w["proj_w"], w["proj_b"], residual=x, out=x, alpha=w["proj_a"])
-                    h = ops.gemm(None, w["fc1_lnr"][0], w["fc1_lnr"][1], a_ln=x, act=ops.ACT_GELU, out_dtype=cdt)
+                    h = ops.gemm(None, w["fc1_lnr"][0], w["fc1_lnr"][1], a_ln=x, act=ops.ACT_GELU, out_dtype=cdt,
+                                 alpha=w["fc1_lnr"][2])
                     ops.gemm(h, w["fc2_w"], w["fc2_b"], residual=x, out=x, alpha=w["fc2_a"])
                 else:
                     xn = ops.layernorm(x, w["n1w"], w["n1b"], out_dtype=cdt)

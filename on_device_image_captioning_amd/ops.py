@@ -268,6 +268,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
 
 
 _A_LN_CANDIDATES = (50, 52, 51, 53)          # the A-resident tile configurations (gemm_bf16_apanel_kernel)
+_A_LN_X3_CANDIDATES = (20, 21)               # gemm_x3_apanel_kernel (K = 192)
 
 
 def _gemm_a_ln(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor], *, act: int,
@@ -275,16 +276,16 @@ def _gemm_a_ln(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], o
     """out = act(alpha·LN0(x)·Wᵀ + bias), LN0 = LayerNorm without affine, computed while the fp32 rows are read
     (odic_gemm_args.a_ln).  x fp32 [M,K] contiguous, W bf16 [N,K] contiguous."""
     _need_cuda(x, W, bias, out)
-    if x.dtype != torch.float32 or W.dtype != torch.bfloat16 or not (x.is_contiguous() and W.is_contiguous()):
-        raise RuntimeError("gemm(a_ln=...): contiguous fp32 rows and a contiguous bf16 weight")
+    if x.dtype != torch.float32 or W.dtype not in (torch.bfloat16, H2_DTYPE) or not (x.is_contiguous() and W.is_contiguous()):
+        raise RuntimeError("gemm(a_ln=...): contiguous fp32 rows and a contiguous bf16 / split-fp16 weight")
     K = x.shape[-1]
     M, N = x.numel() // K, W.shape[0]
     if out is None:
-        out = torch.empty(*x.shape[:-1], N, dtype=out_dtype or torch.bfloat16, device=x.device)
+        out = torch.empty(*x.shape[:-1], N, dtype=out_dtype or W.dtype, device=x.device)
     a = _hip.GemmArgs(None, _p(W), _p(bias), None, _p(out), M, N, K, K, K, 0, N, 1, 0, 0, 0, 0, 0, alpha, act, 0,
-                      BF16, dtype_code(out.dtype), tile_cfg, None, float(ln_eps), None, None, 1.0, None, 0, None, None,
+                      dtype_code(W.dtype), dtype_code(out.dtype), tile_cfg, None, float(ln_eps), None, None, 1.0, None, 0, None, None,
                       _p(x), K)
-    key = ("a_ln", M, N, K, out.dtype, act)
+    key = ("a_ln", W.dtype, M, N, K, out.dtype, act)
     cfg = _TILE_CHOICE.get(key) if tile_cfg < 0 else tile_cfg
     if cfg is None and _TILE_CACHE:
         cfg = _TILE_CACHE.get(_cache_key(key))
@@ -293,17 +294,21 @@ def _gemm_a_ln(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], o
     if cfg is None:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("gemm(a_ln=...): no tile choice for this shape yet — run it once outside graph capture")
-        cfg = _tune_gemm(a, key, out, _A_LN_CANDIDATES)
+        cfg = _tune_gemm(a, key, out, _A_LN_CANDIDATES if W.dtype == torch.bfloat16 else _A_LN_X3_CANDIDATES)
         if cfg < 0:
             raise RuntimeError(f"gemm(a_ln=...): no A-resident tile configuration takes {M}x{N}x{K}")
     a.tile_cfg = cfg
-    with _timed("gemm_bf16", 2.0 * M * N * K, M * K * 4 + N * K * 2 + M * N * out.element_size(), f"ln+{M}x{N}x{K}"):
+    with _timed("gemm_bf16" if W.dtype == torch.bfloat16 else "gemm_x3", 2.0 * M * N * K,
+                M * K * 4 + N * K * W.element_size() + M * N * out.element_size(), f"ln+{M}x{N}x{K}"):
         _hip.check(_hip.load().odic_gemm(C.byref(a), _stream()), "odic_gemm")
     return out
 
 
-def a_ln_supported(M: int, N: int, K: int) -> bool:
-    """Shapes the LayerNorm-while-reading form takes: K = 192 (128-row panels, 64-column chunks) or 384 (128 / 32)."""
+def a_ln_supported(M: int, N: int, K: int, dtype=torch.bfloat16) -> bool:
+    """Shapes the LayerNorm-while-reading form takes: K = 192 (128-row panels, 64-column chunks) or 384 (128 / 32); split
+    fp16: K = 192 (64-row panels, 32-column chunks)."""
+    if dtype == H2_DTYPE:
+        return K == 192 and M % 64 == 0 and N % 32 == 0
     return (K == 192 and M % 128 == 0 and N % 64 == 0) or (K == 384 and M % 128 == 0 and N % 32 == 0)
 
 

@@ -102,6 +102,47 @@ def test_gemm_x3_random_against_fp64(ops, M, N, K, cfg):
     assert torch.equal(got_h2.cpu(), ops.h2_from_f32(got.cpu()))
 
 
+@pytest.mark.parametrize("cfg,bm", [(20, 128), (21, 64)])
+def test_gemm_x3_a_resident_kernels_and_layernorm_while_reading(ops, cfg, bm):
+    """Tile configs 20 / 21 (gemm_x3_apanel_kernel, K = 192): bit-for-bit the tiled kernel's results on split-fp16 A (same
+    MFMAs in the same order), every epilogue of the stage-0 products, fp32 and h2 outputs; then the LayerNorm-while-reading
+    form (a_ln = fp32 rows, A = None) against fp64 LayerNorm → Linear at the fp32-class error of this mode, on rows with
+    mean >> spread and a constant row; shapes that are not whole tiles are refused."""
+    g = torch.Generator().manual_seed(cfg)
+    K = 192
+    for M, N in ((bm * 3, 32 * 5), (bm * 9, 32 * 18)):
+        A, Wt = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+        b = torch.randn(N, generator=g)
+        sc = ops.pow2_scale_for_h2(Wt)
+        Ah, Wh = ops.cast_h2(dev(A)), ops.h2_from_f32(Wt * sc).cuda()
+        for kw in (dict(out_dtype=torch.float32), dict(bias=dev(b), act=1), dict(bias=dev(b), out_dtype=torch.float32, act=2)):
+            got = ops.gemm(Ah, Wh, alpha=1.0 / sc, tile_cfg=cfg, **kw)
+            ref = ops.gemm(Ah, Wh, alpha=1.0 / sc, tile_cfg=0, **kw)
+            assert got.dtype == ref.dtype and torch.equal(got, ref), (cfg, M, N, kw.keys())
+    M, N = bm * 5, 32 * 12
+    # (fp32 LayerNorm: the mean carries ~1 ulp of |mean|, so the normalised row is good to ulp(mean) / spread — rows with
+    #  mean / spread up to ~10 keep the mode's 1e-6 class; the constant row must come out as exactly beta·Wᵀ + b)
+    x = torch.randn(M, K, generator=g) * (0.5 + 3.0 * torch.rand(M, 1, generator=g)) + torch.randn(M, 1, generator=g) * 4.0
+    x[3] = 5.0
+    W, b = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    gamma, beta = 1.0 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    want = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5) @ W.double().T + b.double()
+    Wg, b2, _ = ops.fold_layernorm(dev(W), dev(b), dev(gamma), dev(beta))
+    sc = ops.pow2_scale_for_h2(Wg)
+    Wh = ops.h2_from_f32(Wg.cpu() * sc).cuda()
+    got = ops.gemm(None, Wh, b2, a_ln=dev(x), alpha=1.0 / sc, tile_cfg=cfg, out_dtype=torch.float32)
+    # the normalised rows carry the fp32 rounding of mean / rstd (x has mean 40, spread 1: ~1e-6 relative), then 22-bit operands
+    assert rel_err(got, want) <= 4e-6, rel_err(got, want)
+    assert torch.isfinite(got).all()
+    got_h2 = ops.gemm(None, Wh, b2, a_ln=dev(x), alpha=1.0 / sc, tile_cfg=cfg, act=1)
+    assert got_h2.dtype == ops.H2_DTYPE
+    assert rel_err(ops.h2_to_f32(got_h2.cpu()), torch.nn.functional.gelu(want)) <= 4e-6
+    with pytest.raises(RuntimeError):
+        ops.gemm(None, Wh, b2, a_ln=dev(x[: bm + 16].contiguous()), alpha=1.0 / sc, tile_cfg=cfg)
+    with pytest.raises(RuntimeError):
+        ops.gemm(None, Wh, b2, a_ln=dev(x), alpha=1.0 / sc, tile_cfg=1)
+
+
 def test_gemm_x3_beats_bf16_and_matches_fp32_class(ops):
     """The point of the mode, measured: on the same operands the split-fp16 product is > 1000x closer to fp64 than the
     bf16 product and within a factor of a few of the exact fp32 MFMA product."""
