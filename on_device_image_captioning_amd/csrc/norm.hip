@@ -148,11 +148,18 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
   const int r0 = (int)(tok0 - (long)b0 * per_img);
   const int nvalid = (int)min((long)64, ntok - tok0);
 
-  // weights, transposed on the fly: lanes walk c (conflict-free LDS writes), 32-bit index math only
-  const int CK = C * K;
-  for (int i = tid; i < CK; i += 256) {
-    const int k = i / C, c = i - k * C;
-    wt[i] = w[c * K + k];
+  // weights, transposed on the fly: thread c reads row c of w (K contiguous floats, 16-byte loads when K % 4 == 0) and
+  // writes column c of wt — consecutive lanes, consecutive LDS words; no index division
+  for (int c = tid; c < C; c += 256) {
+    const float* wr = w + (long)c * K;
+    if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+      for (int k = 0; k < K; k += 4) {
+        const float4 v = *(const float4*)(wr + k);
+        wt[(k + 0) * C + c] = v.x; wt[(k + 1) * C + c] = v.y; wt[(k + 2) * C + c] = v.z; wt[(k + 3) * C + c] = v.w;
+      }
+    } else {
+      for (int k = 0; k < K; ++k) wt[k * C + c] = wr[k];
+    }
   }
   // input rows: segment s = (channel, patch row) holds 4 contiguous floats per token
   const int nseg = in_chans * patch;
