@@ -42,21 +42,31 @@ __global__ __launch_bounds__(256) void stcexp_fw_kernel(const float* __restrict_
   }
 }
 
-// grid (ceil(S/64), ngroups, B), block (64, 8): 8 slices of the group's query range, LDS reduce
-__global__ __launch_bounds__(512) void stcexp_colsum_kernel(const float* __restrict__ z,
+// grid (ceil(S/64), ngroups, B), block (64, 16): 16 slices of the group's query range (the 512-query group is 32 rows
+// per thread, requested eight at a time: the loop is a chain of L2 round trips, not bandwidth), LDS reduce
+constexpr int CS_SL = 16;
+__global__ __launch_bounds__(64 * CS_SL) void stcexp_colsum_kernel(const float* __restrict__ z,
                                                             const int* __restrict__ group_start,
                                                             float* __restrict__ colsum,   // [B, G, 2, S]
                                                             int nq, int S) {
   ODIC_ENCODE_PRIO();
-  __shared__ float rp[8][64];
-  __shared__ float rn[8][64];
+  __shared__ float rp[CS_SL][64];
+  __shared__ float rn[CS_SL][64];
   const int s = blockIdx.x * 64 + threadIdx.x;
   const int g = blockIdx.y, b = blockIdx.z, G = gridDim.y;
   const int q0 = group_start[g], q1 = group_start[g + 1];
   const float* zb = z + (long)b * nq * S;
   float sp = 0.f, sn = 0.f;
   if (s < S) {
-    for (int q = q0 + threadIdx.y; q < q1; q += 8) {
+    int q = q0 + threadIdx.y;
+    for (; q + 7 * CS_SL < q1; q += 8 * CS_SL) {            // (fixed order of additions: deterministic)
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = zb[(long)(q + i * CS_SL) * S + s];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { sp += fmaxf(v[i], 0.f); sn += fmaxf(-v[i], 0.f); }
+    }
+    for (; q < q1; q += CS_SL) {
       const float v = zb[(long)q * S + s];
       sp += fmaxf(v, 0.f);
       sn += fmaxf(-v, 0.f);
@@ -68,7 +78,7 @@ __global__ __launch_bounds__(512) void stcexp_colsum_kernel(const float* __restr
   if (threadIdx.y == 0 && s < S) {
     float tp = 0.f, tn = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { tp += rp[i][threadIdx.x]; tn += rn[i][threadIdx.x]; }
+    for (int i = 0; i < CS_SL; ++i) { tp += rp[i][threadIdx.x]; tn += rn[i][threadIdx.x]; }
     colsum[(((long)b * G + g) * 2 + 0) * S + s] = tp;
     colsum[(((long)b * G + g) * 2 + 1) * S + s] = tn;
   }
@@ -134,7 +144,7 @@ static int stcexp_launch(const float* z, const int32_t* enc_len, const int32_t* 
   const long rows = (long)B * nq;
   hipLaunchKernelGGL(stcexp_fw_kernel<OutT>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, enc_len,
                      (OutT*)pos_fw, (OutT*)neg_fw, B, nq, S, (int)ld_fw, eps, scale_fw);
-  hipLaunchKernelGGL(stcexp_colsum_kernel, dim3((S + 63) / 64, ngroups, B), dim3(64, 8), 0, s, z, group_meta,
+  hipLaunchKernelGGL(stcexp_colsum_kernel, dim3((S + 63) / 64, ngroups, B), dim3(64, CS_SL), 0, s, z, group_meta,
                      colsum_ws, nq, S);
   hipLaunchKernelGGL(stcexp_bw_kernel<OutT>, dim3((S + 31) / 32, (unsigned)((ld_bw + 31) / 32), B), dim3(32, 8), 0, s,
                      z, colsum_ws, group_meta + ngroups + 1, (OutT*)pos_bw, (OutT*)neg_bw, nq, S, (int)ld_bw, ngroups,
