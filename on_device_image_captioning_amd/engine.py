@@ -420,12 +420,24 @@ class CaptionerEngine:
                       alpha=self.in_a)                                                                   # [M,d]
         xcat = f(M, L * d)
         z = f(B, nq, S)
-        pf, nf = zc(B, nq, Sp), zc(B, nq, Sp)
-        pb, nb = zc(B, S, nqp), zc(B, S, nqp)
+        # K-padded operands.  odic_stcexp_normalize writes its four outputs out to their leading dimension (zeros in the
+        # padding), so they need no clearing; the three GEMM outputs whose padding columns no launch ever writes are kept
+        # per (shape, stream) and zeroed ONCE — clearing them inside every captured encode pass was seven fill launches
+        ec = lambda *s: torch.empty(*s, dtype=cdt, device=dv)               # noqa: E731
+        pf, nf = ec(B, nq, Sp), ec(B, nq, Sp)
+        pb, nb = ec(B, S, nqp), ec(B, S, nqp)
         colsum = f(B * len(g.num_exp_enc_list) * 2 * S)
-        AT, BT = zc(B, d, nqp), zc(B, d, nqp)
+        key = (B, S, torch.cuda.current_stream(dv).cuda_stream)
+        pads = self._pad_ws.get(key) if hasattr(self, "_pad_ws") else None
+        if pads is None:
+            if torch.cuda.is_current_stream_capturing():      # (a first call under capture: plain per-call buffers)
+                pads = (zc(B, d, nqp), zc(B, d, nqp), zc(B, 2 * d, Sp))
+            else:
+                if not hasattr(self, "_pad_ws"):
+                    self._pad_ws = {}
+                pads = self._pad_ws[key] = (zc(B, d, nqp), zc(B, d, nqp), zc(B, 2 * d, Sp))
+        AT, BT, vabT = pads
         A2, B2 = f(B, S, d), f(B, S, d)
-        vabT = zc(B, 2 * d, Sp)
         key = torch.empty(M, d, dtype=cdt, device=dv)
         ld = L * d
         for i, w in enumerate(self.enc):
