@@ -86,8 +86,12 @@ typedef struct odic_gemm_args {
   int32_t bias_axis;  /* 0: bias[n]   1: bias[m] */
   int32_t in_dtype;   /* dtype of A and W */
   int32_t out_dtype;  /* dtype of out */
-  int32_t tile_cfg;   /* bf16 only: tile configuration (see csrc/gemm_bf16.hip): 0..12 one block per tile,
-                       * 16 + c = config c as a persistent launch (needs `workspace`, batch == 1); -1 = built-in choice */
+  int32_t tile_cfg;   /* tile configuration, -1 = built-in choice.  bf16 (csrc/gemm_bf16.hip): 0, 1, 2, 7, 10 power-of-two tiles,
+                       * 40..47 tiles of 48 x 96 wave patches (144 / 288 rows), 48 / 49 64 x 64, 50..53 the A-resident streaming
+                       * kernels for K = 192 / 384 (whole tiles only; the only ones that take `a_ln`); 3..33 further variants in
+                       * -DODIC_EXPERIMENTAL_GEMM builds (16 + c = config c as a persistent launch: needs `workspace`, batch == 1).
+                       * fp8 / fp16 (gemm_lowp.hip): 0..4, 5..9 = the same on the block-scaled fp8 MFMA.  split fp16 (gemm_x3.hip):
+                       * 0..9, 20 / 21 the A-resident kernels for K = 192.  An unsupported (shape, configuration) pair is refused. */
   /* Optional LayerNorm of the A operand, folded (fp32 skinny-M path only: M <= 192, K % 16 == 0,
    * bias_axis 0).  The caller prepares  W' = W·diag(gamma),  ln_colsum[n] = Σ_k W'[n][k]  and
    * bias' = bias + W·beta, passes W' / bias' as W / bias, and the kernel computes
@@ -114,8 +118,8 @@ typedef struct odic_gemm_args {
    *     packed W / bias as for the fp32 form above; out = act(rstd·(alpha·A·W'ᵀ − mean·ln_colsum) + bias') + residual. */
   void* out16; int64_t ld16; float* stats_out;
   const float* ln_stats;
-  /* LayerNorm of the A operand computed while A is read (bf16 A-resident tile configurations 50-53 only — the K = 192 /
-   * 384 products of Swin stages 0-1; whole tiles, batch == 1): A = NULL and the operand is
+  /* LayerNorm of the A operand computed while A is read (A-resident tile configurations only: bf16 50-53, split fp16 20 / 21 — the
+   * K = 192 / 384 products of Swin stages 0-1; whole tiles, batch == 1): A = NULL and the operand is
    *     (x − mean(x)) / sqrt(var(x) + ln_eps)   of each fp32 row of a_ln [M,K] (ld_aln elements),
    * rounded to bf16 in registers; W and bias are folded by the caller as above (W' = W·diag(gamma), bias' = bias + W·beta), so
    *     out = act(alpha·LayerNorm(x; gamma, beta)·Wᵀ + bias) + residual.

@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256sq_kernel(Params p) {
 #endif  // ODIC_EXPERIMENTAL_GEMM
 
 // =================================================================================================
-// A-resident streaming form for the K = 192 / 384 products of Swin stages 0-1 (tile_cfg 50-52).
+// A-resident streaming form for the K = 192 / 384 products of Swin stages 0-1 (tile_cfg 50-53).
 //
 // Those products (147456 x {576,192,768} x 192, 36864 x {1152,384,1536} x 384 at B = 16) are output-bandwidth-bound —
 // 227-283 MB of traffic for 33-44 GFLOP — and the tiled kernel above spends 1.5-3x the time of a copy of the same

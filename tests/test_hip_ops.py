@@ -453,7 +453,7 @@ def test_gemm_bf16_every_tile_config(ops, cfg):
 
 @pytest.mark.parametrize("cfg,K,bm,bnc", [(50, 192, 256, 64), (52, 192, 128, 64), (51, 384, 128, 32), (53, 384, 128, 64)])
 def test_gemm_bf16_a_resident_streaming_kernels(ops, cfg, K, bm, bnc):
-    """tile_cfg 50-52 (gemm_bf16_apanel_kernel: A rows in registers over the whole K, W chunks streamed through LDS, counted
+    """tile_cfg 50-53 (gemm_bf16_apanel_kernel: A rows in registers over the whole K, W chunks streamed through LDS, counted
     store waits) — against fp64 AND bit-for-bit against the tiled kernel (same MFMA, same K order), over every epilogue
     the Swin stage-0/1 products use, panel / chunk counts that exercise every column-range split (1 chunk per block, uneven
     ranges, several panels per XCD), and a strided output; shapes that are not whole tiles are refused."""
