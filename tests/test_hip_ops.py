@@ -449,6 +449,8 @@ def test_gemm_bf16_every_tile_config(ops, cfg):
         want = torch.nn.functional.gelu(A.double() @ Wt.double().T + b.double())
         got = ops.gemm(dev(A), dev(Wt), dev(b), act=1, out_dtype=torch.bfloat16, tile_cfg=cfg)
         assert_close(got, want, 6e-3, f"cfg{cfg} bf16 out {M}x{N}x{K}")
+        if cfg != 47 and cfg in DEFAULT_BF16_TILE_CFGS:            # (47 sums K in another order; every other default tile: same bits)
+            assert torch.equal(got, ops.gemm(dev(A), dev(Wt), dev(b), act=1, out_dtype=torch.bfloat16, tile_cfg=0)), (cfg, M, N, K)
 
 
 @pytest.mark.parametrize("cfg,K,bm,bnc", [(50, 192, 256, 64), (52, 192, 128, 64), (51, 384, 128, 32), (53, 384, 128, 64)])
