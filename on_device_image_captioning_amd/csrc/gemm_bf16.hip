@@ -1315,12 +1315,9 @@ int launch_cfg(Params& p, int out_dtype, int batch, hipStream_t stream) {
   constexpr int SHMEM = SH_STAGES > SH_RED ? SH_STAGES : SH_RED;
   if (p.K % BK != 0) return ODIC_EINVAL;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
-  // XCD partition: fewest column parts whose W sub-panel (N/pn x K bf16) fits ~2.5 MiB of the 4 MiB L2
-  int pn = 1;
-  while (pn < 8 && pn * 2 <= p.tiles_n && (double)p.N / pn * p.K * 2.0 > 2.5 * 1024 * 1024) pn *= 2;
-  int pm = 8 / pn;
-  while (pm > p.tiles_m && pm > 1) { pm /= 2; pn *= 2; }
-  if (pn > p.tiles_n) { pn = 1; pm = 8; while (pm > p.tiles_m && pm > 1) pm /= 2; pn = 8 / pm; }
+  int pm, pn;                                 // XCD partition: the split with the least fabric traffic (odic_common.h)
+  odic_xcd_partition(p.tiles_m, p.tiles_n, (double)p.M * p.K * 2.0, (double)p.N * p.K * 2.0,
+                     32 * (NWM * NWN * KS <= 4 ? 2 : 1), &pm, &pn);
   p.pm = pm; p.pn = pn;
   int max_rect = 0;
   for (int xm = 0; xm < pm; ++xm)

@@ -480,11 +480,8 @@ int launch(Params& p, int out_dtype, int batch, hipStream_t stream) {
   constexpr int BM = NWM * MI * 16, BN = NWN * NI * 16;
   constexpr int SHMEM = NSTAGE * (BM + BN) * ROWB;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
-  int pn = 1;
-  while (pn < 8 && pn * 2 <= p.tiles_n && (double)p.N / pn * p.K * 4.0 > 2.5 * 1024 * 1024) pn *= 2;
-  int pm = 8 / pn;
-  while (pm > p.tiles_m && pm > 1) { pm /= 2; pn *= 2; }
-  if (pn > p.tiles_n) { pn = 1; pm = 8; while (pm > p.tiles_m && pm > 1) pm /= 2; pn = 8 / pm; }
+  int pm, pn;                                 // XCD partition: the split with the least fabric traffic (odic_common.h)
+  odic_xcd_partition(p.tiles_m, p.tiles_n, (double)p.M * p.K * 4.0, (double)p.N * p.K * 4.0, 32 * (NWM * NWN <= 4 ? 2 : 1), &pm, &pn);
   p.pm = pm; p.pn = pn;
   int max_rect = 0;
   for (int xm = 0; xm < pm; ++xm)

@@ -167,6 +167,33 @@ template <bool FAST> __device__ __forceinline__ float apply_act(float v, int act
   }
 }
 
+// XCD partition of a GEMM's tile grid: pm x pn = 8 rectangles, one per XCD (= per 4 MiB L2; blocks b, b + 8, ... share an
+// XCD).  Every row panel of A is fetched by the pn XCDs of its rectangle row and W by the pm XCDs of its rectangle column,
+// so the split that moves the fewest bytes across the fabric minimises  pn·|A| + pm·|W|;  a W sub-panel that does not fit
+// an L2 share beside the streaming A panels is fetched again by every round of its rectangle.  (Rounds 1-2 only asked for
+// the W sub-panel to fit: with A >> W — fc2: 56 MB of hidden activations against 4.7 MB of weights — that read A two
+// to four times: PMC FETCH_SIZE 3.3x the algorithmic bytes on the split-fp16 fc2.)
+static inline void odic_xcd_partition(int tiles_m, int tiles_n, double a_bytes, double w_bytes, int slots_per_xcd,
+                                      int* pm_out, int* pn_out) {
+  double best = 1e300;
+  int bpm = 0, bpn = 0;
+  for (int pn = 1; pn <= 8; pn *= 2) {
+    const int pm = 8 / pn;
+    if (pn > tiles_n || pm > tiles_m) continue;
+    const long rect = (long)((tiles_m + pm - 1) / pm) * ((tiles_n + pn - 1) / pn);
+    const long rounds = (rect + slots_per_xcd - 1) / slots_per_xcd;
+    const double wf = (w_bytes / pn > 2.5 * 1024 * 1024) ? (double)rounds : 1.0;
+    const double cost = pn * a_bytes + pm * w_bytes * wf;
+    if (cost < best) { best = cost; bpm = pm; bpn = pn; }
+  }
+  if (!bpm) {                                             // fewer tiles than XCDs along both axes: as many row parts as there are
+    bpm = 8;
+    while (bpm > tiles_m && bpm > 1) bpm /= 2;
+    bpn = 8 / bpm;
+  }
+  *pm_out = bpm; *pn_out = bpn;
+}
+
 static inline int odic_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
