@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r02_pmc_traffic.json from two rocprofv3 counter_collection.csv files (FETCH_SIZE pass, WRITE_SIZE
+"""profiles/r03_pmc_traffic_<workload>_<mode>.json from two rocprofv3 counter_collection.csv files (FETCH_SIZE pass, WRITE_SIZE
 pass): HBM bytes per launch of each kernel family bench.py reports = (2·FETCH_SIZE + WRITE_SIZE)·1024 (gfx950
 correction of MI355X_MICROARCH.md §HBM).    python tools/pmc_traffic_json.py fetch.csv write.csv out.json "<cmd>" """
 import csv
