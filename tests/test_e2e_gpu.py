@@ -996,3 +996,30 @@ def test_image_chunked_stages_give_the_same_features_bit_for_bit(precision):
             assert float((out - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (chunks, float((out - ref).abs().max()))
         else:
             assert torch.equal(out, ref), (precision, chunks, float((out - ref).abs().max()))
+
+
+def test_fused_stage0_launches_leave_the_backbone_features_unchanged():
+    """The round-3 fusions of the width-192 stage at the engine level (Swin-L, B = 2): norm1 → qkv → attention core as ONE
+    launch must not change the bf16 backbone features by a bit against LayerNorm-while-reading product + attention core
+    (the kernels agree bit for bit: tests/test_hip_ops.py::test_swin_qkv_attention_fused); LayerNorm-while-reading against
+    the separate odic_layernorm launches changes the rounding pattern of the normalised rows only (gamma folded into the
+    bf16 weights): features within the bf16 mode's own error against fp32."""
+    from on_device_image_captioning_amd.engine import SwinEngine
+    g = W.FULL
+    sd = cached_state_dict("FULL", "xavier")
+    img = W.synth_images(2, g, seed=91).to(DEV)
+    eng = SwinEngine(sd, g, torch.device(DEV), "bf16")
+    assert eng.ln_read and eng.fuse_qkv_attn and "qkv_lnr" in eng.stages[0][0][0] and "qkv_lnr" not in eng.stages[1][0][0]
+    fused = eng.forward(img).clone()
+    eng.fuse_qkv_attn = False
+    two = eng.forward(img).clone()
+    assert torch.equal(fused, two), float((fused - two).abs().max())
+    saved = [(w.pop("qkv_lnr"), w.pop("fc1_lnr")) for w in eng.stages[0][0]]
+    plain = eng.forward(img).clone()
+    for w, (a, b) in zip(eng.stages[0][0], saved):
+        w["qkv_lnr"], w["fc1_lnr"] = a, b
+    ref = SwinEngine(sd, g, torch.device(DEV), "fp32").forward(img)
+    scale = float(ref.abs().max())
+    e_fused, e_plain = float((fused - ref).abs().max()) / scale, float((plain - ref).abs().max()) / scale
+    _diag("stage0_fusion_feature_err_vs_fp32", {"fused": e_fused, "separate_layernorm": e_plain})
+    assert e_fused <= 1.5 * e_plain + 1e-3 and e_fused <= 3e-2, (e_fused, e_plain)
